@@ -1,0 +1,169 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle).  Not part of the shipped library.
+ *
+ * CPU restatement of the cascaded PSD hot path of quartiq/stabilizer-stream
+ * (src/psd.rs: Window, Detrend, Psd, PsdStage, Break, MergeOpts, AvgOpts,
+ * PsdCascade) plus src/var.rs Var::eval and the AdcDac payload decode
+ * (src/de/frame.rs, src/de/data.rs:11-82).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this.  The shipped library (stabilizer-stream_amd/csrc) never does.
+ *
+ * PARITY STATUS
+ *   - window, detrend, segment loop, EWMA, overlap, drain, gain, stitch,
+ *     frequencies: restated line by line from src/psd.rs (cited inline) and
+ *     pinned by the reference's own known answers (tests/golden/reference_*.json:
+ *     N=4 Hann [16/3,4/3,0] src/psd.rs:588-595; Hann constants :49-54; length
+ *     relation :622; white-noise bounds :623-643; Var 0.13478442 src/var.rs:55-59).
+ *   - FFT: rustfft 6.4.1 is not in the container; the forward unnormalised DFT
+ *     is mathematically defined (src/psd.rs:213, :279-283) and checked against
+ *     numpy.  Rounding differs at the 1e-7 level.
+ *   - half-band decimator: idsp 0.20.0 is not in the container.  Taps and
+ *     response length are restated from the published crate (hbf_taps_oracle.h);
+ *     PARITY UNPINNED for exact decimator output samples, pinned only by the
+ *     reference's statistical assertions.
+ *   - The Rust reference cannot be built here (no rustc/cargo; dependencies
+ *     not vendored): there is no oracle/_ref.
+ *
+ * Two instantiations: *_f32 mirrors the reference's f32 arithmetic (compile
+ * with -ffp-contract=off: rustc does not fuse a*b+c), *_f64 is the truth.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#include "hbf_taps_oracle.h"
+
+/* Break (src/psd.rs:290-311) with bins: Range<usize> flattened */
+typedef struct {
+    uint64_t start;
+    uint32_t include;
+    uint32_t count;
+    uint32_t avg;
+    uint32_t _pad;
+    uint64_t bins_start, bins_end;
+    uint64_t fft_size;
+    uint64_t decimation;
+    uint64_t pending;
+    uint64_t processed;
+} ora_break;
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+#define REAL float
+#define SFX(name) CAT(name, _f32)
+#define R_IS_F32 1
+#include "psd_oracle_impl.h"
+#undef REAL
+#undef SFX
+#undef R_IS_F32
+
+#define REAL double
+#define SFX(name) CAT(name, _f64)
+#define R_IS_F32 0
+#include "psd_oracle_impl.h"
+#undef REAL
+#undef SFX
+#undef R_IS_F32
+
+int ora_hbf_response_length(int depth) { return ora_hbf_dec_response_length(depth); }
+
+/* Break::frequencies (src/psd.rs:315-327), rbw (:334-336) in f32 */
+long ora_frequencies(const ora_break *b, int n, float *out)
+{
+    long len = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!b[i].include)
+            continue;
+        const float rbw = 1.0f / (float)(b[i].fft_size * b[i].decimation);
+        for (uint64_t f = b[i].bins_start; f < b[i].bins_end; ++f)
+            out[len++] = (float)f * rbw;
+    }
+    return len;
+}
+
+/* Var::eval (src/var.rs:26-45), f32 like the reference.
+ * defaults: x_exp=-2, sinx_exp=4, clip=f32::MAX, dc_cut=2 (src/var.rs:7-17) */
+static float powi_f32(float x, int e)
+{
+    /* f32::powi: repeated multiplication (llvm.powi); negative -> reciprocal */
+    int neg = e < 0;
+    unsigned u = (unsigned)(neg ? -e : e);
+    float r = 1.0f, b = x;
+    while (u) {
+        if (u & 1u)
+            r *= b;
+        b *= b;
+        u >>= 1;
+    }
+    return neg ? 1.0f / r : r;
+}
+
+float ora_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const float *phase_psd,
+                   const float *frequencies, size_t n, float tau)
+{
+    float accu = 0.0f, a0 = 0.0f, f0 = 0.0f;
+    const float pi = 3.14159265358979323846f;
+    for (size_t i = dc_cut; i < n; ++i) {
+        const float f = frequencies[i], sp = phase_psd[i];
+        if (!(f <= clip / tau))
+            break; /* take_while */
+        const float sy = sp * f * f;
+        const float pft = pi * (f * tau);
+        const float hahd = powi_f32(sinf(pft), sinx_exp) * powi_f32(pft, x_exp);
+        const float a = sy * hahd;
+        accu = accu + (a + a0) * (f - f0);
+        a0 = a;
+        f0 = f;
+    }
+    return accu;
+}
+
+/* ---- AdcDac frame decode (src/de/frame.rs:5-37,49-60; src/de/data.rs:11-82)
+ * returns 0 ok; -1 InvalidHeader; -2 UnknownFormat; -3 PayloadSize;
+ * -4 would panic in the reference (len<8, or len/64 != batches); -5 other format.
+ * traces: 4 arrays (ADC0, ADC1, DAC0, DAC1) of 8*batches f32 each. */
+int ora_adcdac_decode(const uint8_t *frame, size_t len, float *adc0, float *adc1, float *dac0,
+                      float *dac1, uint32_t *seq, uint32_t *batches)
+{
+    if (len < 8)
+        return -4; /* input[..HEADER_SIZE] panics (frame.rs:50) */
+    if (frame[0] != 0x7b || frame[1] != 0x05)
+        return -1; /* frame.rs:27-29 */
+    const uint8_t fmt = frame[2];
+    if (fmt < 1 || fmt > 4)
+        return -2; /* frame.rs:30 */
+    const uint32_t nb = frame[3];
+    *seq = (uint32_t)frame[4] | ((uint32_t)frame[5] << 8) | ((uint32_t)frame[6] << 16) |
+           ((uint32_t)frame[7] << 24);
+    *batches = nb;
+    if (fmt != 1)
+        return -5;
+    const size_t plen = len - 8;
+    if (plen % 64 != 0)
+        return -3; /* bytemuck::try_cast_slice (data.rs:23) */
+    if (plen / 64 != nb)
+        return -4; /* assert_eq!(data.len(), batches) (data.rs:24) */
+    /* data.rs:31-35 */
+    const float lsb = 4.096f * 2.5f / 32768.0f;
+    float *tr[4] = {adc0, adc1, dac0, dac1};
+    const uint8_t *p = frame + 8;
+    for (uint32_t b = 0; b < nb; ++b) {
+        for (int ch = 0; ch < 4; ++ch) {
+            for (int i = 0; i < 8; ++i) {
+                const uint8_t *q = p + ((size_t)b * 4 + (size_t)ch) * 16 + (size_t)i * 2;
+                int16_t v = (int16_t)((uint16_t)q[0] | ((uint16_t)q[1] << 8));
+                if (ch >= 2) /* i16.wrapping_add(i16::MIN) (data.rs:64,75) */
+                    v = (int16_t)((uint16_t)v + 0x8000u);
+                tr[ch][(size_t)b * 8 + (size_t)i] = (float)v * lsb;
+            }
+        }
+    }
+    return 0;
+}
