@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Throughput of the cascaded PSD hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of PsdCascade<1024> over one batch of 2^26 synthetic raw-f32
+samples already resident in HBM (BASELINE.json configs[1]: 1-channel raw f32,
+N=1024, >= 6 stages).  With N > 1 GPUs (one process per GPU under
+torch.distributed.run) every rank runs the same workload on its own channel
+(weak scaling, channels shard with no data-path collective) and the final
+per-stage spectra are gathered to rank 0 over RCCL inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3
+ALG_BYTES_PER_SAMPLE = 4.0   # each raw f32 sample crosses HBM once
+ALG_FLOP_PER_SAMPLE = {1024: 78.0, 4096: 89.0, 16384: 100.0}
+
+
+def cpu_baseline(n, seconds=12.0):
+    """Time the CPU oracle (C restatement, f32) on this host: one thread, process() calls of
+    65536 samples like the reference's `insn` bench (src/psd.rs:554-559)."""
+    ora = entry.load_oracle()
+    pkg = entry.load_package()
+    x = pkg.noise_host(1 << 16, 0x7654321)
+    c = ora.PsdCascade(n, "f32")
+    c.process(x)  # warm
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(16):
+            c.process(x)
+        done += 16 * x.size
+    dt = time.perf_counter() - t0
+    return {"value": done / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{done} samples ({done // x.size} process() calls of 65536) in {dt:.1f} s, "
+                      f"C restatement of src/psd.rs (oracle/, f32, gcc -O3 -march=native), not the Rust crate; "
+                      f"reference quotes >200 MS/s/core for N=512 (README.md:11)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1024, help="FFT size N")
+    ap.add_argument("--log2-batch", type=int, default=26, help="samples per channel per step = 2^this")
+    ap.add_argument("--channels-per-gpu", type=int, default=1)
+    ap.add_argument("--detrend", default="none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the PSD path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = entry.load_package()
+    n, C = args.n, args.channels_per_gpu
+    T = 1 << args.log2_batch
+    bank = pkg.PsdCascadeBank(n, C, device=local_rank)
+    bank.set_detrend(pkg.Detrend[args.detrend.upper()])
+    # synthetic raw-f32 streams, generated on the device: channel c of rank r uses seed 0x7654321 + global channel
+    bufs = []
+    for c in range(C):
+        d = torch.empty(T, dtype=torch.float32, device="cuda")
+        pkg.fill_noise_device(d.data_ptr(), T, seed=0x7654321 + rank * C + c, device=local_rank)
+        bufs.append(d)
+    torch.cuda.synchronize()
+
+    def step():
+        for c in range(C):
+            bank.process_device(c, bufs[c].data_ptr(), T)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        bank.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    bank.configure(profile=True)
+    bank.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    # read-out: every rank's raw per-stage spectra to rank 0 (one RCCL gather), then host stitch
+    ns = bank.num_stages(0)
+    kmax = 12
+    spec = torch.zeros(C, kmax, n // 2 + 1, dtype=torch.float32)
+    meta = torch.zeros(C, kmax, 2, dtype=torch.int64)
+    for c in range(C):
+        for k in range(bank.num_stages(c)):
+            spec[c, k] = torch.from_numpy(bank.stage_spectrum(c, k))
+            info = bank.stage_info(c, k)
+            meta[c, k, 0], meta[c, k, 1] = info["count"], info["pending"]
+    if dist is not None:
+        spec_d, meta_d = spec.cuda(), meta.cuda()
+        gs = [torch.empty_like(spec_d) for _ in range(world)] if rank == 0 else None
+        gm = [torch.empty_like(meta_d) for _ in range(world)] if rank == 0 else None
+        dist.gather(spec_d, gs, dst=0)
+        dist.gather(meta_d, gm, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    prof = bank.profile_read()
+    if rank == 0:
+        total_samples = float(args.steps) * T * C * world
+        msps = total_samples / dt / 1e6
+        psd, breaks = bank.psd(0)
+        reached = sum(1 for b in breaks if b.include)
+        kern_s = prof["kernel_ms"] * 1e-3
+        ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
+        flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
+        out = {
+            "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,
+            "value": msps, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{C * world}-channel raw f32 stream ({C} per GPU), PsdCascade N={n}, Hann, "
+                                   f"detrend {args.detrend}, 2^{args.log2_batch} samples/channel/step resident in HBM, "
+                                   f"{ns} stages instantiated ({reached} with count>=1)",
+                       "fft_size": n, "channels": C * world, "samples_per_step_per_channel": T,
+                       "stages": ns, "parallelism": f"channel-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "welch_kernel", "launches": prof["launches"],
+                         "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
+                         "algorithmic_bytes_per_sample": ALG_BYTES_PER_SAMPLE},
+            "compute_roofline": {"bound": "fp32_valu", "achieved": flop * msps * 1e6 / 1e12 / world,
+                                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flop * msps * 1e6 / 1e12 / world / FP32_VALU_PEAK_TFLOPS,
+                                 "algorithmic_flop_per_sample": flop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(out))
+    bank.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,237 @@
+/*
+ * psdcascade.h -- C ABI of the MI355X-native cascaded PSD estimator.
+ *
+ * Drop-in boundary for the hot path of quartiq/stabilizer-stream src/psd.rs
+ * (`Psd<N>` / `PsdCascade<N>`).  The reference has no FFI of its own; the
+ * boundary is the Rust type surface its binaries use.
+ * Each entry point below names the reference item it replaces (file:line under
+ * the reference checkout).  INTEGRATION.md shows the Rust `extern "C"` shim and
+ * the `PsdCascade<N>` wrapper a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - opaque handle, plain pointers and sizes, int status: 0 ok, <0 error
+ *     (PSDC_ERR_*).  Nothing unwinds across the ABI.  Where the reference
+ *     panics on misuse (assert!/unimplemented!, src/psd.rs:110,138,139,247) the
+ *     call returns an error and `psdc_last_error` describes it; the Rust shim
+ *     turns that back into panic!.
+ *   - a handle is used from one thread at a time (like `&mut self`); it may be
+ *     moved between threads (Send, not Sync).  Distinct handles are independent.
+ *   - one handle holds `n_channels` independent cascades (one `PsdCascade` per
+ *     trace, src/bin/psd.rs:174-182) that are batched onto one GPU.
+ *   - all sample data is IEEE f32, native endian (src/bin/stream_to_raw.rs:24-25).
+ *   - there is NO CPU fallback: without a usable HIP device `psdc_create` fails.
+ */
+#ifndef PSDCASCADE_H
+#define PSDCASCADE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSDC_ABI_VERSION 1
+
+/* status codes */
+#define PSDC_OK 0
+#define PSDC_ERR_ARG (-1)           /* bad argument (reference: assert!/index panic) */
+#define PSDC_ERR_DEVICE (-2)        /* HIP error / no device */
+#define PSDC_ERR_NOMEM (-3)
+#define PSDC_ERR_UNIMPLEMENTED (-4) /* Detrend::Linear: unimplemented!() src/psd.rs:110 */
+#define PSDC_ERR_FRAME_HEADER (-5)  /* de::Error::InvalidHeader  src/de/frame.rs:27-29 */
+#define PSDC_ERR_FRAME_FORMAT (-6)  /* de::Error::UnknownFormat  src/de/frame.rs:30 */
+#define PSDC_ERR_FRAME_SIZE (-7)    /* de::Error::PayloadSize / batches mismatch src/de/data.rs:23-24 */
+#define PSDC_ERR_CAPACITY (-8)      /* caller-provided output too small */
+
+/* Window<N> constructors (src/psd.rs:24-32, :42-55) */
+#define PSDC_WINDOW_RECTANGULAR 0
+#define PSDC_WINDOW_HANN 1
+
+/* Detrend (src/psd.rs:59-72) */
+#define PSDC_DETREND_NONE 0
+#define PSDC_DETREND_MIDPOINT 1
+#define PSDC_DETREND_SPAN 2
+#define PSDC_DETREND_MEAN 3
+#define PSDC_DETREND_LINEAR 4 /* accepted by the enum, rejected like the reference */
+
+/* DEPTH (src/psd.rs:117): each stage decimates by 1 << 3 */
+#define PSDC_DEPTH 3
+
+/* options for psdc_configure */
+#define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
+#define PSDC_OPT_PROFILE 2 /* 1: bracket the dominant kernel with HIP events (psdc_profile_read) */
+
+typedef struct psdc_handle psdc_handle;
+
+/* Break (src/psd.rs:290-311); `bins: Range<usize>` is flattened. */
+typedef struct psdc_break {
+    uint64_t start;      /* start index in PSD and frequencies */
+    uint32_t include;    /* was included in output */
+    uint32_t count;      /* number of averages */
+    uint32_t avg;        /* averaging limit */
+    uint32_t _pad;
+    uint64_t bins_start; /* FFT bins [bins_start, bins_end) */
+    uint64_t bins_end;
+    uint64_t fft_size;
+    uint64_t decimation;
+    uint64_t pending;    /* unprocessed input samples (includes overlap) */
+    uint64_t processed;  /* total samples processed (excluding overlap) */
+} psdc_break;
+
+/* PsdStage accessors (src/psd.rs:271-287) + Break bookkeeping in one record */
+typedef struct psdc_stage_stat {
+    uint32_t count; /* PsdStage::count  src/psd.rs:275-277 */
+    uint32_t avg;   /* Psd::avg         src/psd.rs:133 */
+    uint64_t pending;   /* PsdStage::buf().len()  src/psd.rs:285-287 */
+    uint64_t processed; /* src/psd.rs:511-512 */
+} psdc_stage_stat;
+
+typedef struct psdc_profile {
+    uint64_t launches;      /* dominant-kernel launches bracketed so far */
+    double kernel_ms;       /* sum of their HIP-event durations */
+    uint64_t samples;       /* input samples those launches consumed (all stages) */
+    uint64_t stage0_samples;/* of which stage-0 (raw stream) samples */
+} psdc_profile;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+
+/* PsdCascade::<N>::default() (src/psd.rs:408-423) for `n_channels` traces on HIP
+ * device `device`.  n: power of two, 16 <= n <= 16384 (the reference takes any
+ * N >= 2 with (N - overlap) % 8 == 0, src/psd.rs:138,247; this build ships the
+ * fixed power-of-two FFT sizes).  Returns NULL on failure; psdc_last_error(NULL)
+ * explains. */
+psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
+
+/* Drop (src/bin/psd.rs:190 `dec.clear()`). */
+void psdc_destroy(psdc_handle *h);
+
+/* #[derive(Clone)] (src/psd.rs:399): deep copy of every channel's state. */
+psdc_handle *psdc_clone(psdc_handle *h);
+
+/* Cmd::Reset (src/bin/psd.rs:190): forget all stages of all channels, keep settings. */
+int psdc_reset(psdc_handle *h);
+
+int psdc_configure(psdc_handle *h, int option, int64_t value);
+
+/* ---- settings ------------------------------------------------------------ */
+
+/* PsdCascade::set_detrend (src/psd.rs:438-443); applies to segments completed
+ * after the call (pending complete segments are flushed first). */
+int psdc_set_detrend(psdc_handle *h, int detrend_kind);
+
+/* PsdCascade::set_avg(AvgOpts{limit, count}) (src/psd.rs:431-436); stage i uses
+ * min(count >> (3 i), limit). */
+int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count);
+
+/* ---- ingest -------------------------------------------------------------- */
+
+/* PsdCascade::process(&[f32]) (src/psd.rs:456-468) for one channel.  `x` is host
+ * memory and is copied before returning.  GPU work may be deferred until
+ * PSDC_OPT_QUANTUM samples are buffered or a read-out/flush happens; results
+ * depend only on the concatenated stream, not on call chunking. */
+int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len);
+
+/* Same, but `d_x` is device memory on the handle's device and is read in place
+ * (no staging copy).  The work is enqueued asynchronously: `d_x` must stay
+ * valid and unmodified until psdc_sync()/any read-out returns. */
+int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size_t len);
+
+/* Frame::from_bytes + AdcDac::traces (src/de/frame.rs:49-60, src/de/data.rs:11-82)
+ * + process() of the four traces ADC0, ADC1, DAC0, DAC1 into channels 0..3
+ * (src/bin/psd.rs:174-182), for `n_frames` frames of `frame_size` bytes each,
+ * as read by Source::get for Data::File (src/source.rs:135-142).  Host memory.
+ * Headers are validated on the host; payloads are de-interleaved on the device.
+ * On a bad frame: frames before it are ingested, *n_ok says how many, and the
+ * frame's de::Error is returned.  Needs n_channels >= 4. */
+int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
+                               size_t n_frames, size_t *n_ok);
+
+/* Enqueue every complete segment of every stage now (does not wait). */
+int psdc_flush(psdc_handle *h);
+
+/* Wait until all enqueued device work of this handle has finished. */
+int psdc_sync(psdc_handle *h);
+
+/* ---- read-out (each implies flush + sync) -------------------------------- */
+
+/* PsdCascade.stages.len() (src/psd.rs:401,445-453): stages are created when
+ * the first sample reaches them. */
+int psdc_num_stages(psdc_handle *h, uint32_t channel);
+
+int psdc_stage_info(psdc_handle *h, uint32_t channel, uint32_t stage, psdc_stage_stat *out);
+
+/* PsdStage::spectrum (src/psd.rs:271-273): n/2+1 un-normalised accumulators. */
+int psdc_stage_spectrum(psdc_handle *h, uint32_t channel, uint32_t stage, float *out);
+
+/* PsdStage::gain (src/psd.rs:279-283). */
+int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out);
+
+/* PsdStage::buf (src/psd.rs:285-287): the pending input samples of a stage. */
+int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out, size_t cap,
+                   size_t *len);
+
+/* PsdCascade::psd(&MergeOpts) (src/psd.rs:479-543).  psd_out needs room for
+ * num_stages*(n/2+1) floats, breaks for num_stages records (lowest rate first).
+ * Either output pointer may be NULL to query sizes only. */
+int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_count,
+             int keep_transition_band, float *psd_out, size_t psd_cap, size_t *psd_len,
+             psdc_break *breaks, size_t breaks_cap, size_t *n_breaks);
+
+/* PsdCascade::rbw (src/psd.rs:427-429). */
+float psdc_rbw(const psdc_handle *h);
+
+/* ---- pure host helpers (no device needed) -------------------------------- */
+
+/* Break::frequencies (src/psd.rs:315-327).  Returns the number written, or the
+ * number required if out is NULL / cap too small. */
+size_t psdc_frequencies(const psdc_break *breaks, size_t n_breaks, float *out, size_t cap);
+
+/* idsp::hbf::hbf_dec_response_length(depth) (src/psd.rs:149,622). */
+int psdc_hbf_response_length(int depth);
+
+/* The stitch of PsdCascade::psd (src/psd.rs:479-543) on caller-provided stage
+ * data: spectra is n_stages rows of (n/2+1) floats, stage 0 (highest rate)
+ * first; window_kind selects nenbw/power/overlap.  Used by psdc_psd and by
+ * multi-GPU read-out after a gather of raw spectra. */
+int psdc_stitch(uint32_t n, int window_kind, uint32_t n_stages, const uint32_t *counts,
+                const uint32_t *avgs, const uint64_t *pendings, const float *spectra,
+                int keep_overlap, uint32_t min_count, int keep_transition_band, float *psd_out,
+                size_t psd_cap, size_t *psd_len, psdc_break *breaks, size_t breaks_cap,
+                size_t *n_breaks);
+
+/* Stream bookkeeping of src/psd.rs:196-269 in closed form: after `total`
+ * samples have entered stage 0, how many stages exist and, per stage, samples
+ * received, segments completed (= count when averaging is unbounded) and
+ * pending samples.  Arrays hold up to `cap` stages. Returns the stage count. */
+int psdc_plan_counts(uint32_t n, int window_kind, uint64_t total, uint32_t cap,
+                     uint64_t *received, uint64_t *segments, uint64_t *pending);
+
+/* Var::eval (src/var.rs:26-45) on a merged PSD (host, f32). */
+float psdc_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const float *phase_psd,
+                    const float *frequencies, size_t n, float tau);
+
+/* ---- device utilities ---------------------------------------------------- */
+
+/* HbfDec8 block processing (src/psd.rs:246-253) of a whole host array from zero
+ * state on the device: y[m], m < len/8.  Standalone check of the decimator. */
+int psdc_hbf_dec8(int device, const float *x, size_t len, float *y);
+
+/* Fill device memory with the bench/test stream: x_i = (u_i - 0.5) * sqrt(12),
+ * u_i = (splitmix64(seed + first_index + i) >> 40) * 2^-24  (unit-variance
+ * uniform noise, the reference's own test signal src/psd.rs:604-606). */
+int psdc_fill_noise_device(int device, float *d_x, size_t len, uint64_t seed,
+                           uint64_t first_index);
+
+int psdc_profile_read(psdc_handle *h, psdc_profile *out, int reset);
+
+/* Last error text of a handle; with h == NULL, of the calling thread's last
+ * failed psdc_create / handle-less call. */
+const char *psdc_last_error(const psdc_handle *h);
+
+int psdc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSDCASCADE_H */

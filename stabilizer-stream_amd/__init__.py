@@ -1,0 +1,483 @@
+"""MI355X-native cascaded PSD estimator -- Python mirror of the reference surface.
+
+Thin ctypes layer over the C ABI in include/psdcascade.h (libpsdcascade.so, HIP
+kernels for gfx950).  Class and method names follow quartiq/stabilizer-stream
+src/psd.rs so that tests read like the reference's own:
+
+    PsdCascade(n)            PsdCascade::<N>::default()        src/psd.rs:408-423
+      .set_detrend(Detrend)  PsdCascade::set_detrend           src/psd.rs:438-443
+      .set_avg(AvgOpts)      PsdCascade::set_avg               src/psd.rs:431-436
+      .process(x)            PsdCascade::process               src/psd.rs:456-468
+      .psd(MergeOpts)        PsdCascade::psd -> (psd, breaks)  src/psd.rs:479-543
+    Break.frequencies(b)     Break::frequencies                src/psd.rs:315-327
+
+There is no CPU fallback: constructing a PsdCascade without a HIP device raises.
+The directory name carries a hyphen; import it through `__graft_entry__.load_package()`
+or tests/conftest.py (module name `stabilizer_stream_amd`).
+"""
+import ctypes as C
+import enum
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsdcascade.so")
+U32_MAX = 0xFFFFFFFF
+
+PSDC_OK = 0
+ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNIMPLEMENTED = -1, -2, -3, -4
+ERR_FRAME_HEADER, ERR_FRAME_FORMAT, ERR_FRAME_SIZE, ERR_CAPACITY = -5, -6, -7, -8
+OPT_QUANTUM, OPT_PROFILE = 1, 2
+
+
+class PsdError(RuntimeError):
+    """A contract violation the reference would panic on, or a device error."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"psdcascade error {code}: {msg}")
+        self.code = code
+
+
+class FrameError(PsdError):
+    """de::Error (src/de/mod.rs:19-27)."""
+
+
+class Detrend(enum.IntEnum):
+    """src/psd.rs:59-72"""
+    NONE = 0
+    MIDPOINT = 1
+    SPAN = 2
+    MEAN = 3
+    LINEAR = 4
+
+
+class Window(enum.IntEnum):
+    """Window::rectangular / Window::hann (src/psd.rs:24-55)"""
+    RECTANGULAR = 0
+    HANN = 1
+
+
+@dataclass(frozen=True)
+class MergeOpts:
+    """src/psd.rs:339-358"""
+    keep_overlap: bool = False
+    min_count: int = 1
+    keep_transition_band: bool = False
+
+
+@dataclass(frozen=True)
+class AvgOpts:
+    """src/psd.rs:360-376"""
+    limit: int = U32_MAX
+    count: int = U32_MAX
+
+
+class _CBreak(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("include", C.c_uint32), ("count", C.c_uint32),
+                ("avg", C.c_uint32), ("_pad", C.c_uint32),
+                ("bins_start", C.c_uint64), ("bins_end", C.c_uint64),
+                ("fft_size", C.c_uint64), ("decimation", C.c_uint64),
+                ("pending", C.c_uint64), ("processed", C.c_uint64)]
+
+
+class _CStageStat(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("avg", C.c_uint32),
+                ("pending", C.c_uint64), ("processed", C.c_uint64)]
+
+
+class _CProfile(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("kernel_ms", C.c_double),
+                ("samples", C.c_uint64), ("stage0_samples", C.c_uint64)]
+
+
+@dataclass(frozen=True)
+class Break:
+    """Stage break information (src/psd.rs:290-311)."""
+    start: int
+    include: bool
+    count: int
+    avg: int
+    bins: range
+    fft_size: int
+    decimation: int
+    pending: int
+    processed: int
+
+    def effective_fft_size(self):  # src/psd.rs:329-331
+        return self.fft_size * self.decimation
+
+    def rbw(self):  # src/psd.rs:334-336
+        return float(np.float32(1.0) / np.float32(self.effective_fft_size()))
+
+    def _c(self):
+        return _CBreak(self.start, int(self.include), self.count, self.avg, 0, self.bins.start,
+                       self.bins.stop, self.fft_size, self.decimation, self.pending, self.processed)
+
+    @staticmethod
+    def _from_c(b):
+        return Break(int(b.start), bool(b.include), int(b.count), int(b.avg),
+                     range(int(b.bins_start), int(b.bins_end)), int(b.fft_size),
+                     int(b.decimation), int(b.pending), int(b.processed))
+
+    @staticmethod
+    def frequencies(breaks):
+        """Break::frequencies (src/psd.rs:315-327)."""
+        L = lib()
+        arr = (_CBreak * max(1, len(breaks)))(*[b._c() for b in breaks])
+        n = L.psdc_frequencies(arr, len(breaks), None, 0)
+        out = np.empty(n, dtype=np.float32)
+        L.psdc_frequencies(arr, len(breaks), out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return out
+
+
+def build(force=False, verbose=False):
+    """Compile libpsdcascade.so for gfx950 with hipcc (csrc/Makefile)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                          "(there is no Python/CPU fallback for the PSD kernels)")
+    L = C.CDLL(LIB_PATH)
+    H, u32, u64, i32, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
+    fp = C.POINTER(C.c_float)
+
+    def f(name, res, args):
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+
+    f("psdc_abi_version", i32, [])
+    f("psdc_last_error", C.c_char_p, [H])
+    f("psdc_create", H, [u32, i32, u32, i32])
+    f("psdc_destroy", None, [H])
+    f("psdc_clone", H, [H])
+    f("psdc_reset", i32, [H])
+    f("psdc_configure", i32, [H, i32, C.c_int64])
+    f("psdc_set_detrend", i32, [H, i32])
+    f("psdc_set_avg", i32, [H, u32, u32])
+    f("psdc_process", i32, [H, u32, fp, sz])
+    f("psdc_process_device", i32, [H, u32, C.c_void_p, sz])
+    f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
+    f("psdc_flush", i32, [H])
+    f("psdc_sync", i32, [H])
+    f("psdc_num_stages", i32, [H, u32])
+    f("psdc_stage_info", i32, [H, u32, u32, C.POINTER(_CStageStat)])
+    f("psdc_stage_spectrum", i32, [H, u32, u32, fp])
+    f("psdc_stage_gain", i32, [H, u32, u32, fp])
+    f("psdc_stage_buf", i32, [H, u32, u32, fp, sz, C.POINTER(sz)])
+    f("psdc_psd", i32, [H, u32, i32, u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz,
+                        C.POINTER(sz)])
+    f("psdc_rbw", C.c_float, [H])
+    f("psdc_frequencies", sz, [C.POINTER(_CBreak), sz, fp, sz])
+    f("psdc_hbf_response_length", i32, [i32])
+    f("psdc_stitch", i32, [u32, i32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), fp, i32,
+                           u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz, C.POINTER(sz)])
+    f("psdc_plan_counts", i32, [u32, i32, u64, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)])
+    f("psdc_var_eval", C.c_float, [i32, i32, C.c_float, sz, fp, fp, sz, C.c_float])
+    f("psdc_hbf_dec8", i32, [i32, fp, sz, fp])
+    f("psdc_fill_noise_device", i32, [i32, C.c_void_p, sz, u64, u64])
+    f("psdc_profile_read", i32, [H, C.POINTER(_CProfile), i32])
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "psdc_abi_version", "psdc_last_error", "psdc_create", "psdc_destroy", "psdc_clone", "psdc_reset",
+    "psdc_configure", "psdc_set_detrend", "psdc_set_avg", "psdc_process", "psdc_process_device",
+    "psdc_process_adcdac_frames", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
+    "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_psd", "psdc_rbw",
+    "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
+    "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
+]
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _raise(code, h=None):
+    msg = lib().psdc_last_error(h)
+    msg = msg.decode() if msg else ""
+    cls = FrameError if code in (ERR_FRAME_HEADER, ERR_FRAME_FORMAT, ERR_FRAME_SIZE) else PsdError
+    raise cls(code, msg)
+
+
+class PsdCascadeBank:
+    """`n_channels` independent PsdCascade<N> batched on one GPU (one handle of the C ABI)."""
+
+    def __init__(self, n, n_channels=1, window=Window.HANN, device=0, _handle=None):
+        self.n, self.n_channels, self.window, self.device = n, n_channels, Window(window), device
+        self._L = lib()
+        self._h = _handle if _handle is not None else self._L.psdc_create(n, int(window), n_channels, device)
+        if not self._h:
+            _raise(ERR_DEVICE)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.psdc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc < 0:
+            _raise(rc, self._h)
+        return rc
+
+    def clone(self):
+        h = self._L.psdc_clone(self._h)
+        if not h:
+            _raise(ERR_DEVICE)
+        return PsdCascadeBank(self.n, self.n_channels, self.window, self.device, _handle=h)
+
+    def reset(self):
+        self._ck(self._L.psdc_reset(self._h))
+
+    def configure(self, quantum=None, profile=None):
+        if quantum is not None:
+            self._ck(self._L.psdc_configure(self._h, OPT_QUANTUM, int(quantum)))
+        if profile is not None:
+            self._ck(self._L.psdc_configure(self._h, OPT_PROFILE, int(bool(profile))))
+
+    def rbw(self):
+        return float(self._L.psdc_rbw(self._h))
+
+    def set_detrend(self, d):
+        self._ck(self._L.psdc_set_detrend(self._h, int(d)))
+
+    def set_avg(self, avg):
+        self._ck(self._L.psdc_set_avg(self._h, avg.limit, avg.count))
+
+    def process(self, channel, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self._ck(self._L.psdc_process(self._h, channel, _fptr(x), x.size))
+
+    def process_device(self, channel, ptr, length):
+        """ptr: device address (e.g. torch tensor .data_ptr()) of `length` f32 samples."""
+        self._ck(self._L.psdc_process_device(self._h, channel, C.c_void_p(ptr), length))
+
+    def process_adcdac_frames(self, data, frame_size):
+        """data: bytes-like holding whole frames; returns the number of frames ingested."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        n_frames = buf.size // frame_size
+        ok = C.c_size_t(0)
+        rc = self._L.psdc_process_adcdac_frames(self._h, buf.ctypes.data_as(C.c_void_p), frame_size,
+                                                n_frames, C.byref(ok))
+        if rc < 0:
+            _raise(rc, self._h)
+        return ok.value
+
+    def flush(self):
+        self._ck(self._L.psdc_flush(self._h))
+
+    def sync(self):
+        self._ck(self._L.psdc_sync(self._h))
+
+    def num_stages(self, channel=0):
+        return self._ck(self._L.psdc_num_stages(self._h, channel))
+
+    def stage_info(self, channel, stage):
+        st = _CStageStat()
+        self._ck(self._L.psdc_stage_info(self._h, channel, stage, C.byref(st)))
+        return {"count": st.count, "avg": st.avg, "pending": st.pending, "processed": st.processed}
+
+    def stage_spectrum(self, channel, stage):
+        out = np.empty(self.n // 2 + 1, dtype=np.float32)
+        self._ck(self._L.psdc_stage_spectrum(self._h, channel, stage, _fptr(out)))
+        return out
+
+    def stage_gain(self, channel, stage):
+        g = C.c_float()
+        self._ck(self._L.psdc_stage_gain(self._h, channel, stage, C.byref(g)))
+        return g.value
+
+    def stage_buf(self, channel, stage):
+        ln = C.c_size_t()
+        self._ck(self._L.psdc_stage_buf(self._h, channel, stage, None, 0, C.byref(ln)))
+        out = np.empty(ln.value, dtype=np.float32)
+        self._ck(self._L.psdc_stage_buf(self._h, channel, stage, _fptr(out), out.size, C.byref(ln)))
+        return out
+
+    def psd(self, channel=0, opts=MergeOpts()):
+        ns = self.num_stages(channel)
+        out = np.empty(max(1, ns * (self.n // 2 + 1)), dtype=np.float32)
+        br = (_CBreak * max(1, ns))()
+        plen, nb = C.c_size_t(), C.c_size_t()
+        self._ck(self._L.psdc_psd(self._h, channel, int(opts.keep_overlap), opts.min_count,
+                                  int(opts.keep_transition_band), _fptr(out), out.size, C.byref(plen),
+                                  br, ns, C.byref(nb)))
+        return out[:plen.value].copy(), [Break._from_c(br[i]) for i in range(nb.value)]
+
+    def profile_read(self, reset=False):
+        p = _CProfile()
+        self._ck(self._L.psdc_profile_read(self._h, C.byref(p), int(reset)))
+        return {"launches": p.launches, "kernel_ms": p.kernel_ms, "samples": p.samples,
+                "stage0_samples": p.stage0_samples}
+
+
+class PsdCascade:
+    """Online cascaded PSD estimator, one trace (src/psd.rs:399-544)."""
+
+    def __init__(self, n, window=Window.HANN, device=0, _bank=None):
+        self.n = n
+        self._b = _bank if _bank is not None else PsdCascadeBank(n, 1, window, device)
+
+    def clone(self):
+        return PsdCascade(self.n, _bank=self._b.clone())
+
+    def rbw(self):
+        return self._b.rbw()
+
+    def set_avg(self, avg):
+        self._b.set_avg(avg)
+
+    def set_detrend(self, d):
+        self._b.set_detrend(d)
+
+    def process(self, x):
+        self._b.process(0, x)
+
+    def process_device(self, ptr, length):
+        self._b.process_device(0, ptr, length)
+
+    def psd(self, opts=MergeOpts()):
+        return self._b.psd(0, opts)
+
+    # PsdStage accessors of stage i (src/psd.rs:271-287)
+    def num_stages(self):
+        return self._b.num_stages(0)
+
+    def stage_spectrum(self, i):
+        return self._b.stage_spectrum(0, i)
+
+    def stage_gain(self, i):
+        return self._b.stage_gain(0, i)
+
+    def stage_count(self, i):
+        return self._b.stage_info(0, i)["count"]
+
+    def stage_buf(self, i):
+        return self._b.stage_buf(0, i)
+
+    def stage_info(self, i):
+        return self._b.stage_info(0, i)
+
+    def configure(self, **kw):
+        self._b.configure(**kw)
+
+    def sync(self):
+        self._b.sync()
+
+    def close(self):
+        self._b.close()
+
+
+# ---- pure host helpers (no device) -----------------------------------------
+
+def hbf_response_length(depth=3):
+    """idsp::hbf::hbf_dec_response_length (src/psd.rs:149,622)."""
+    return lib().psdc_hbf_response_length(depth)
+
+
+def plan_counts(n, total, window=Window.HANN, cap=32):
+    """Closed-form (received, segments, pending) per stage after `total` samples."""
+    r = (C.c_uint64 * cap)()
+    s = (C.c_uint64 * cap)()
+    p = (C.c_uint64 * cap)()
+    k = lib().psdc_plan_counts(n, int(window), total, cap, r, s, p)
+    if k < 0:
+        _raise(k)
+    return [(int(r[i]), int(s[i]), int(p[i])) for i in range(min(k, cap))]
+
+
+def stitch(n, counts, avgs, pendings, spectra, opts=MergeOpts(), window=Window.HANN):
+    """PsdCascade::psd (src/psd.rs:479-543) on gathered per-stage data (stage 0 first)."""
+    L = lib()
+    ns = len(counts)
+    cc = (C.c_uint32 * max(1, ns))(*counts)
+    aa = (C.c_uint32 * max(1, ns))(*avgs)
+    pp = (C.c_uint64 * max(1, ns))(*pendings)
+    sp = np.ascontiguousarray(spectra, dtype=np.float32).reshape(ns, n // 2 + 1) if ns else np.zeros((1, 1), np.float32)
+    out = np.empty(max(1, ns * (n // 2 + 1)), dtype=np.float32)
+    br = (_CBreak * max(1, ns))()
+    plen, nb = C.c_size_t(), C.c_size_t()
+    rc = L.psdc_stitch(n, int(window), ns, cc, aa, pp, _fptr(sp), int(opts.keep_overlap),
+                       opts.min_count, int(opts.keep_transition_band), _fptr(out), out.size,
+                       C.byref(plen), br, ns, C.byref(nb))
+    if rc < 0:
+        _raise(rc)
+    return out[:plen.value].copy(), [Break._from_c(br[i]) for i in range(nb.value)]
+
+
+def var_eval(phase_psd, frequencies, tau, x_exp=-2, sinx_exp=4, clip=3.4028234663852886e38, dc_cut=2):
+    """Var::eval (src/var.rs:26-45) with VarBuilder defaults (src/var.rs:7-17)."""
+    p = np.ascontiguousarray(phase_psd, dtype=np.float32)
+    f = np.ascontiguousarray(frequencies, dtype=np.float32)
+    return float(lib().psdc_var_eval(x_exp, sinx_exp, clip, dc_cut, _fptr(p), _fptr(f), p.size, tau))
+
+
+def hbf_dec8(x, device=0):
+    """HbfDec8 block processing from zero state on the device (src/psd.rs:246-253)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(x.size // 8, dtype=np.float32)
+    rc = lib().psdc_hbf_dec8(device, _fptr(x), x.size, _fptr(y))
+    if rc < 0:
+        _raise(rc)
+    return y
+
+
+def fill_noise_device(ptr, length, seed, first_index=0, device=0):
+    rc = lib().psdc_fill_noise_device(device, C.c_void_p(ptr), length, seed, first_index)
+    if rc < 0:
+        _raise(rc)
+
+
+def noise_host(length, seed, first_index=0):
+    """Host twin of psdc_fill_noise_device: (u - 0.5) * sqrt(12), u from splitmix64 (src/psd.rs:604-606)."""
+    i = (np.arange(length, dtype=np.uint64) + np.uint64(first_index) + np.uint64(seed))
+    with np.errstate(over="ignore"):
+        x = i + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+    return ((u - np.float32(0.5)) * np.float32(3.4641016151377544)).astype(np.float32)
+
+
+# ---- feed side (src/source.rs, src/de): byte formats only -------------------
+
+ADCDAC_TRACES = ("ADC0", "ADC1", "DAC0", "DAC1")  # src/de/data.rs:37-80
+
+
+def make_adcdac_frames(traces_i16, batches, seq0=0):
+    """Serialise four int16 traces into AdcDac frames (src/de/frame.rs:5-37, data.rs:13).
+
+    traces_i16: array [4, n_samples] of the RAW wire words (the DAC words are
+    offset-binary on the wire, src/de/data.rs:64).  n_samples must be a multiple
+    of 8*batches.  Returns (bytes, frame_size)."""
+    t = np.ascontiguousarray(traces_i16, dtype="<i2")
+    assert t.shape[0] == 4 and t.shape[1] % (8 * batches) == 0 and 0 < batches < 256
+    nf = t.shape[1] // (8 * batches)
+    frame_size = 8 + 64 * batches
+    out = np.zeros((nf, frame_size), dtype=np.uint8)
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3] = 0x7B, 0x05, 1, batches
+    seq = (seq0 + np.arange(nf, dtype=np.uint64) * batches).astype("<u4")
+    out[:, 4:8] = seq.view(np.uint8).reshape(nf, 4)
+    # payload: frame, batch, channel, 8 samples
+    pay = t.reshape(4, nf, batches, 8).transpose(1, 2, 0, 3)
+    out[:, 8:] = np.ascontiguousarray(pay).view(np.uint8).reshape(nf, 64 * batches)
+    return out.tobytes(), frame_size

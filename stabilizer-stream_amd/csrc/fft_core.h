@@ -1,0 +1,272 @@
+// fft_core.h -- fixed-N forward complex FFT for a "team" of N/E threads, E
+// elements per thread in registers, radix-<=16 decimation-in-frequency passes
+// exchanged in place through an LDS frame.
+//
+// Replaces the rustfft call of the reference (src/psd.rs:213, plan :418):
+// unnormalised forward DFT X[k] = sum_j c[j] exp(-2 pi i jk/N).  Only
+// |X[k]|^2 is consumed (src/psd.rs:228-233), so the output is left in
+// digit-reversed position and the last pass may rotate its inputs (unit phase).
+//
+// Everything here is __host__ __device__: tests/host/fft_emul.cpp runs the
+// same code lane by lane on the CPU to check the index maps without a GPU.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PSDK_HD __host__ __device__ __forceinline__
+#else
+#define PSDK_HD inline
+#endif
+
+namespace psdk {
+
+struct alignas(8) cf {
+    float re, im;
+};
+
+PSDK_HD cf cadd(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+PSDK_HD cf csub(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+PSDK_HD cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PSDK_HD cf mul_mi(cf a) { return {a.im, -a.re}; } // a * (-i)
+
+// a * exp(-2 pi i k16/16), k16 compile-time
+template <int K16>
+PSDK_HD cf mul_w16(cf a)
+{
+    constexpr int k = ((K16 % 16) + 16) % 16;
+    constexpr float r = 0.70710678118654752440f;
+    constexpr float c1 = 0.92387953251128675613f; // cos(pi/8)
+    constexpr float s1 = 0.38268343236508977173f; // sin(pi/8)
+    if constexpr (k == 0) return a;
+    else if constexpr (k == 4) return {a.im, -a.re};
+    else if constexpr (k == 8) return {-a.re, -a.im};
+    else if constexpr (k == 12) return {-a.im, a.re};
+    else if constexpr (k == 2) return {(a.re + a.im) * r, (a.im - a.re) * r};
+    else if constexpr (k == 6) return {(a.im - a.re) * r, -(a.re + a.im) * r};
+    else if constexpr (k == 10) return {-(a.re + a.im) * r, (a.re - a.im) * r};
+    else if constexpr (k == 14) return {(a.re - a.im) * r, (a.re + a.im) * r};
+    else {
+        // w = cos(k pi/8) - i sin(k pi/8)
+        constexpr float wr = (k == 1 || k == 15) ? c1 : (k == 3 || k == 13) ? s1
+                           : (k == 5 || k == 11) ? -s1 : -c1;
+        constexpr float wi = (k == 1 || k == 7) ? -s1 : (k == 3 || k == 5) ? -c1
+                           : (k == 9 || k == 15) ? s1 : c1;
+        return {a.re * wr - a.im * wi, a.re * wi + a.im * wr};
+    }
+}
+
+// In-register DFT of R points, natural-order output.
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<1> {
+    static PSDK_HD void run(cf *) {}
+};
+
+template <>
+struct Dft<2> {
+    static PSDK_HD void run(cf *v)
+    {
+        cf a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <>
+struct Dft<4> {
+    static PSDK_HD void run(cf *v)
+    {
+        cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        cf t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[2] = csub(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[3] = csub(t1, t3);
+    }
+};
+
+// R = 4 * B (B = 2 or 4): radix-4 over the high index, constant twiddles
+// W_R^(m0 q1), then radix-B over the low index; output q = q1 + 4 q0.
+template <int R>
+struct Dft {
+    static_assert(R == 8 || R == 16, "radix");
+    static constexpr int A = 4, B = R / 4;
+
+    template <int M0, int Q1>
+    static PSDK_HD cf tw(cf a)
+    {
+        return mul_w16<M0 * Q1 * (16 / R)>(a);
+    }
+
+    template <int M0>
+    static PSDK_HD void col(const cf *v, cf *y)
+    {
+        cf t[A];
+#pragma unroll
+        for (int m1 = 0; m1 < A; ++m1)
+            t[m1] = v[m1 * B + M0];
+        Dft<A>::run(t);
+        y[0 * B + M0] = t[0];
+        y[1 * B + M0] = tw<M0, 1>(t[1]);
+        y[2 * B + M0] = tw<M0, 2>(t[2]);
+        y[3 * B + M0] = tw<M0, 3>(t[3]);
+    }
+
+    static PSDK_HD void run(cf *v)
+    {
+        cf y[R];
+        col<0>(v, y);
+        col<1>(v, y);
+        if constexpr (B == 4) {
+            col<2>(v, y);
+            col<3>(v, y);
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < A; ++q1) {
+            cf t[B];
+#pragma unroll
+            for (int m0 = 0; m0 < B; ++m0)
+                t[m0] = y[q1 * B + m0];
+            Dft<B>::run(t);
+#pragma unroll
+            for (int q0 = 0; q0 < B; ++q0)
+                v[q1 + A * q0] = t[q0];
+        }
+    }
+};
+
+// Radix plan: E elements per thread, passes of radix min(E, remaining).
+template <int N>
+struct FftPlan {
+    static_assert(N >= 16 && (N & (N - 1)) == 0, "N must be a power of two >= 16");
+    static constexpr int E = N >= 256 ? 16 : 4;
+    static constexpr int TEAM = N / E;
+
+    static constexpr int len(int p) // sub-transform length entering pass p
+    {
+        int rem = N;
+        for (int i = 0; i < p; ++i)
+            rem /= (rem < E ? rem : E);
+        return rem;
+    }
+    static constexpr int radix(int p) { return len(p) < E ? len(p) : E; }
+    static constexpr int npass()
+    {
+        int p = 0;
+        while (len(p) > 1)
+            ++p;
+        return p;
+    }
+    static constexpr int NPASS = npass();
+};
+
+template <int N, int P>
+struct PassInfo {
+    using Plan = FftPlan<N>;
+    static constexpr int E = Plan::E;
+    static constexpr int TEAM = Plan::TEAM;
+    static constexpr int L = Plan::len(P);
+    static constexpr int R = Plan::radix(P);
+    static constexpr int S = L / R;  // stride between the R inputs of a butterfly
+    static constexpr int NB = E / R; // butterflies per thread
+    static constexpr bool LAST = (P == Plan::NPASS - 1);
+
+    // natural element index held in register slot (i, m) of team-thread t
+    static PSDK_HD int elem(int t, int i, int m)
+    {
+        const int u = t + i * TEAM;
+        const int b = u / S, s = u % S;
+        return b * L + s + m * S;
+    }
+};
+
+// LDS frame swizzle (index in complex elements).  Chosen per N so that the
+// b64 accesses of every pass are bank-conflict free (tests/host/fft_emul.cpp
+// counts conflicts with the gfx950 banking rules).
+template <int N>
+PSDK_HD int lds_swz(int idx)
+{
+    if constexpr (N == 1024)
+        return idx ^ ((idx >> 4) & 0x1C);
+    else
+        return idx;
+}
+
+// Frequency bin held at natural position `pos` after all DIF passes:
+// pos = sum_p d_p * N/(R_0..R_p)  ->  k = sum_p d_p * (R_0..R_{p-1}).
+template <int N>
+PSDK_HD int freq_of_pos(int pos)
+{
+    using Plan = FftPlan<N>;
+    int k = 0, mul = 1, rem = N;
+#pragma unroll
+    for (int p = 0; p < Plan::NPASS; ++p) {
+        const int r = Plan::radix(p);
+        rem /= r;
+        const int d = (pos / rem) % r;
+        k += d * mul;
+        mul *= r;
+    }
+    return k;
+}
+
+// butterflies + inter-pass twiddles of pass P on the thread's registers.
+// tw: table of W_N^j = exp(-2 pi i j/N), j < N.
+template <int N, int P>
+PSDK_HD void pass_compute(int t, cf *v, const cf *tw)
+{
+    using PI = PassInfo<N, P>;
+#pragma unroll
+    for (int i = 0; i < PI::NB; ++i) {
+        Dft<PI::R>::run(v + i * PI::R);
+        if constexpr (PI::S > 1) {
+            const int u = t + i * PI::TEAM;
+            const int s = u % PI::S;
+#pragma unroll
+            for (int q = 1; q < PI::R; ++q)
+                v[i * PI::R + q] = cmul(v[i * PI::R + q], tw[(s * q) * (N / PI::L)]);
+        }
+    }
+}
+
+// write the outputs of pass P in place into the team's LDS frame
+template <int N, int P>
+PSDK_HD void pass_store(int t, const cf *v, cf *frame)
+{
+    using PI = PassInfo<N, P>;
+#pragma unroll
+    for (int i = 0; i < PI::NB; ++i)
+#pragma unroll
+        for (int q = 0; q < PI::R; ++q)
+            frame[lds_swz<N>(PI::elem(t, i, q))] = v[i * PI::R + q];
+}
+
+// read the inputs of pass P from the team's LDS frame.  In the LAST pass the
+// inputs may be rotated by `rot` positions within the butterfly: the outputs
+// then differ by a unit phase only, which |X|^2 does not see.
+template <int N, int P>
+PSDK_HD void pass_load(int t, cf *v, const cf *frame, int rot = 0)
+{
+    using PI = PassInfo<N, P>;
+#pragma unroll
+    for (int i = 0; i < PI::NB; ++i)
+#pragma unroll
+        for (int m = 0; m < PI::R; ++m) {
+            const int mm = PI::LAST ? ((m + rot) % PI::R) : m;
+            v[i * PI::R + m] = frame[lds_swz<N>(PI::elem(t, i, mm))];
+        }
+}
+
+// frequency bin of register slot `slot` of team-thread t after the last pass
+template <int N>
+PSDK_HD int freq_of_slot(int t, int slot)
+{
+    using PI = PassInfo<N, FftPlan<N>::NPASS - 1>;
+    const int i = slot / PI::R, q = slot % PI::R;
+    return freq_of_pos<N>(PI::elem(t, i, q));
+}
+
+} // namespace psdk

@@ -1,0 +1,97 @@
+// kernels.h -- launch interface between the host runtime (psdcascade.cpp) and
+// the gfx950 kernels (kernels.hip).  Job descriptors travel by value in the
+// kernel argument segment (no descriptor copies, graph-capturable).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "fft_core.h"
+
+namespace psdk {
+
+constexpr int MAX_JOBS = 12;
+
+// One span of consecutive segments of one (channel, stage) stream.
+struct SegJob {
+    const float *src;    // sample with absolute stream index i is src[i - src_base]
+    long long src_base;
+    long long seg0;      // absolute index of the first segment (segment j starts at j*hop)
+    float *partial;      // [ntiles][n] power partials, natural bin order
+    double log2_gamma;   // EWMA: log2(avg/(avg+1)); -inf when avg == 0
+    int nseg;            // segments in this span
+    int tile_begin;      // first tile of this job within the launch
+    int step0;           // EWMA: 1-based batch step of seg0
+    int nb;              // EWMA: steps in the whole (channel, stage) batch
+    int is_m1;           // EWMA: i_s - 1
+    int ewma;            // 0: plain sum (all weights 1)
+};
+
+struct WelchBatch {
+    int njobs;
+    int ntiles;
+    int hop;
+    int detrend;
+    SegJob jobs[MAX_JOBS];
+};
+
+// One span of /8 decimator outputs of one (channel, stage) stream.
+struct DecJob {
+    const float *src;
+    long long src_base;
+    long long m0;        // first decimator output index (output m consumes inputs 8m..8m+7)
+    float *dst;          // next stage's stream: output m lands at dst[(m - drain) - dst_base]
+    long long dst_base;
+    int nout;
+    int tile_begin;
+};
+
+struct DecBatch {
+    int njobs;
+    int ntiles;
+    int drain;
+    DecJob jobs[MAX_JOBS];
+};
+
+// Fold the partials of one (channel, stage) into its spectrum accumulator:
+// spectrum[k] = g_total*spectrum[k] + 0.5*sum_t (P[t][k] + P[t][(n-k)%n]).
+struct RedJob {
+    const float *partial;
+    float *spectrum;
+    float g_total;
+    int ntiles;
+};
+
+struct RedBatch {
+    int njobs;
+    int n;
+    RedJob jobs[MAX_JOBS];
+};
+
+// Carry the unconsumed tail of a stream to the front of its other buffer.
+struct TailJob {
+    const float *src;
+    float *dst;
+    int count;
+};
+
+struct TailBatch {
+    int njobs;
+    TailJob jobs[MAX_JOBS];
+};
+
+// tile geometry (host needs it to size partial slabs and grids)
+int welch_segments_per_tile(int n);
+constexpr int DEC_TILE = 256; // decimator outputs per workgroup
+
+bool welch_supported(int n);
+hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
+hipError_t launch_dec(const DecBatch &b, hipStream_t s);
+hipError_t launch_reduce(const RedBatch &b, hipStream_t s);
+hipError_t launch_tail(const TailBatch &b, hipStream_t s);
+hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);
+// frames: device copy of n_frames frames of frame_size bytes (AdcDac, `batches`
+// batches each); dst[c] receives 8*batches*n_frames samples of trace c.
+hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,
+                         float *dst0, float *dst1, float *dst2, float *dst3, hipStream_t s);
+
+} // namespace psdk

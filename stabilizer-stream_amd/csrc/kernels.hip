@@ -1,0 +1,495 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the cascaded PSD hot path.
+//
+//   welch_kernel<N>   detrend + window (src/psd.rs:75-113), forward FFT
+//                     (src/psd.rs:213) and |X|^2 accumulation (src/psd.rs:228-233)
+//                     for a tile of 50%-overlapped segments; two real segments
+//                     ride one complex FFT (re = segment j, im = segment j+1).
+//   hbf_dec8_kernel   the /8 half-band cascade (src/psd.rs:246-253) on blocks
+//                     with a recomputed halo, drain applied on store (:255-260).
+//   reduce_kernel     folds per-tile power partials into the stage accumulator
+//                     with the batch EWMA factor (src/psd.rs:218-233).
+//   tail/fill/adcdac  stream carry, synthetic noise, AdcDac payload decode
+//                     (src/de/data.rs:11-82).
+//
+// No MFMA: the path is FP32-VALU / LDS bound.  64-wide
+// wavefronts throughout; LDS frames are exchanged with 8-byte accesses.
+#include "kernels.h"
+#include "hbf_taps.h"
+
+namespace psdk {
+
+// ---------------------------------------------------------------------------
+// Welch kernel
+// ---------------------------------------------------------------------------
+
+template <int N>
+struct WelchCfg {
+    using Plan = FftPlan<N>;
+    static constexpr int E = Plan::E;
+    static constexpr int TEAM = Plan::TEAM;                 // threads per FFT
+    static constexpr int BLOCK = TEAM > 256 ? TEAM : 256;   // threads per workgroup
+    static constexpr int TEAMS = BLOCK / TEAM;              // concurrent FFTs per workgroup
+    static constexpr int SPT = (2 * TEAMS * 4 > 32) ? 2 * TEAMS * 4 : 32; // segments per tile
+    static constexpr int WAVES = BLOCK / 64;
+};
+
+__device__ __forceinline__ float ewma_amp(const SegJob &job, int step)
+{
+    // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
+    const int m = step > job.is_m1 ? step : job.is_m1;
+    const int na = job.nb - m;
+    if (na <= 0)
+        return 1.0f;
+    return (float)exp2(0.5 * (double)na * job.log2_gamma); // log2_gamma = -inf -> 0
+}
+
+template <int N, int P>
+__device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__restrict__ tw)
+{
+    using PI = PassInfo<N, P>;
+    if constexpr (P > 0) {
+        int rot = 0;
+        if constexpr (N == 1024 && PI::LAST)
+            rot = (t >> 3) & (PI::R - 1); // bank-conflict-free last-pass reads
+        pass_load<N, P>(t, v, frame, rot);
+    }
+    pass_compute<N, P>(t, v, tw);
+    if constexpr (!PI::LAST) {
+        if constexpr (P == 0)
+            __syncthreads(); // previous iteration's last-pass reads are done
+        pass_store<N, P>(t, v, frame);
+        __syncthreads();
+        fft_passes<N, P + 1>(t, v, frame, tw);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBatch batch,
+                                                                  const float *__restrict__ win,
+                                                                  const cf *__restrict__ tw)
+{
+    using Cfg = WelchCfg<N>;
+    using P0 = PassInfo<N, 0>;
+    constexpr int E = Cfg::E, TEAM = Cfg::TEAM, TEAMS = Cfg::TEAMS, SPT = Cfg::SPT;
+
+    __shared__ cf frames[TEAMS * N];
+    __shared__ float red[Cfg::WAVES * 2];
+
+    // tile -> job
+    const int tile = blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < batch.njobs && tile >= batch.jobs[ji + 1].tile_begin)
+        ++ji;
+    const SegJob &job = batch.jobs[ji];
+    const int lt = tile - job.tile_begin;
+    const int seg_lo = lt * SPT;
+    const int seg_hi = min(job.nseg, seg_lo + SPT);
+    const int npairs = (seg_hi - seg_lo + 1) >> 1;
+
+    const int team = threadIdx.x / TEAM;
+    const int t = threadIdx.x % TEAM;
+    cf *frame = frames + team * N;
+    const int hop = batch.hop;
+    const int detrend = batch.detrend;
+
+    float q[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s)
+        q[s] = 0.0f;
+
+    for (int p0 = 0; p0 < npairs; p0 += TEAMS) {
+        const int p = p0 + team;
+        const int la = seg_lo + 2 * p; // local segment index of the "real" lane
+        const bool act_a = la < seg_hi, act_b = la + 1 < seg_hi;
+        const float *xa = job.src + ((job.seg0 + la) * (long long)hop - job.src_base);
+        const float *xb = xa + hop;
+
+        float ra[E], rb[E];
+#pragma unroll
+        for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+            for (int m = 0; m < P0::R; ++m) {
+                const int nidx = P0::elem(t, i, m);
+                ra[i * P0::R + m] = act_a ? xa[nidx] : 0.0f;
+                rb[i * P0::R + m] = act_b ? xb[nidx] : 0.0f;
+            }
+
+        // Detrend (src/psd.rs:75-113): offset(n) = o0 + n * sl
+        float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f;
+        if (detrend == 1) { // Midpoint :87-93
+            oa = act_a ? xa[N / 2] : 0.0f;
+            ob = act_b ? xb[N / 2] : 0.0f;
+        } else if (detrend == 2) { // Span :94-102 (ramp evaluated as o0 + n*slope)
+            if (act_a) {
+                oa = xa[0];
+                sa = (xa[N - 1] - oa) / (float)(N - 1);
+            }
+            if (act_b) {
+                ob = xb[0];
+                sb = (xb[N - 1] - ob) / (float)(N - 1);
+            }
+        } else if (detrend == 3) { // Mean :103-109
+            float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                pa += ra[s];
+                pb += rb[s];
+            }
+            constexpr int W = TEAM < 64 ? TEAM : 64;
+#pragma unroll
+            for (int o = W / 2; o > 0; o >>= 1) {
+                pa += __shfl_xor(pa, o);
+                pb += __shfl_xor(pb, o);
+            }
+            if constexpr (TEAM > 64) {
+                // one team per workgroup here: combine its waves through LDS
+                const int w = threadIdx.x >> 6;
+                if ((threadIdx.x & 63) == 0) {
+                    red[2 * w] = pa;
+                    red[2 * w + 1] = pb;
+                }
+                __syncthreads();
+                pa = 0.0f;
+                pb = 0.0f;
+                for (int i = 0; i < Cfg::WAVES; ++i) {
+                    pa += red[2 * i];
+                    pb += red[2 * i + 1];
+                }
+                __syncthreads();
+            }
+            oa = pa / (float)N;
+            ob = pb / (float)N;
+        }
+
+        float ampa = 1.0f, ampb = 1.0f;
+        if (job.ewma) {
+            ampa = ewma_amp(job, job.step0 + la);
+            ampb = ewma_amp(job, job.step0 + la + 1);
+        }
+
+        cf v[E];
+#pragma unroll
+        for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+            for (int m = 0; m < P0::R; ++m) {
+                const int s = i * P0::R + m;
+                const int nidx = P0::elem(t, i, m);
+                const float w = win[nidx];
+                float a = ra[s], b = rb[s];
+                if (detrend != 0) {
+                    a -= fmaf((float)nidx, sa, oa);
+                    b -= fmaf((float)nidx, sb, ob);
+                }
+                a *= w;
+                b *= w;
+                if (job.ewma) {
+                    a *= ampa;
+                    b *= ampb;
+                }
+                v[s].re = a;
+                v[s].im = b;
+            }
+
+        fft_passes<N, 0>(t, v, frame, tw);
+
+#pragma unroll
+        for (int s = 0; s < E; ++s)
+            q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+    }
+
+    // combine the teams and write the tile's partial in natural bin order
+    float *fq = reinterpret_cast<float *>(frames);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < E; ++s)
+        fq[team * N + freq_of_slot<N>(t, s)] = q[s];
+    __syncthreads();
+    float *out = job.partial + (size_t)lt * N;
+    for (int k = threadIdx.x; k < N; k += Cfg::BLOCK) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < TEAMS; ++g)
+            acc += fq[g * N + k];
+        out[k] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// /8 half-band decimator
+// ---------------------------------------------------------------------------
+
+__constant__ float c_taps_a[HBF_MA] = {PSDK_HBF_TAPS_A};
+__constant__ float c_taps_b[HBF_MB] = {PSDK_HBF_TAPS_B};
+__constant__ float c_taps_c[HBF_MC] = {PSDK_HBF_TAPS_C};
+
+// Block geometry for DEC_TILE outputs starting at output index mt0 (see
+// hbf_taps.h for the per-stage spans); every block origin is even so that the
+// even/odd polyphase split of each stage input is aligned.
+namespace dec {
+constexpr int B_PRE = HBF_PRE_B; // 58: B0 = 2*mt0 - B_PRE
+constexpr int A_PRE = HBF_PRE_A; // 138: A0 = 4*mt0 - A_PRE
+constexpr int X_PRE = HBF_HALO;  // 288: X0 = 8*mt0 - X_PRE
+static_assert(2 * A_PRE + HBF_SPAN_A <= X_PRE, "halo too small");
+constexpr int NB_OUT = 2 * DEC_TILE + B_PRE; // 570
+constexpr int NA_OUT = 4 * DEC_TILE + A_PRE; // 1162
+constexpr int NX = 8 * DEC_TILE + X_PRE;     // 2336
+// polyphase index offsets: out j -> even in[j + CE], odd in[j + CO + i] and in[j + CO + 2M-1-i]
+constexpr int A_D = X_PRE / 2 - A_PRE;       // A0 - X0/2 = 6
+constexpr int A_CE = A_D - HBF_MA + 1, A_CO = A_D - 2 * HBF_MA + 1;
+constexpr int B_D = A_PRE / 2 - B_PRE;       // 11
+constexpr int B_CE = B_D - HBF_MB + 1, B_CO = B_D - 2 * HBF_MB + 1;
+constexpr int C_D = B_PRE / 2;               // 29
+constexpr int C_CE = C_D - HBF_MC + 1, C_CO = C_D - 2 * HBF_MC + 1;
+static_assert(A_CO >= 0 && B_CO >= 0 && C_CO >= 0, "negative polyphase offset");
+} // namespace dec
+
+template <int M>
+__device__ __forceinline__ float hbf_point(const float *__restrict__ ev, const float *__restrict__ od,
+                                           const float *taps, int j, int ce, int co)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+        acc += (od[j + co + i] + od[j + co + 2 * M - 1 - i]) * taps[i];
+    return ev[j + ce] + acc;
+}
+
+__global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
+{
+    using namespace dec;
+    __shared__ float xe[NX / 2], xo[NX / 2];
+    __shared__ float ae[NA_OUT / 2], ao[NA_OUT / 2];
+    __shared__ float be[NB_OUT / 2], bo[NB_OUT / 2];
+
+    const int tile = blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < batch.njobs && tile >= batch.jobs[ji + 1].tile_begin)
+        ++ji;
+    const DecJob &job = batch.jobs[ji];
+    const int lt = tile - job.tile_begin;
+    const long long mt0 = job.m0 + (long long)lt * DEC_TILE;
+    const int nvalid = (int)min((long long)DEC_TILE, job.m0 + job.nout - mt0);
+    const long long x0 = 8 * mt0 - X_PRE;
+    const long long x_end = 8 * (mt0 + nvalid); // inputs at or beyond are not needed
+    const int tid = threadIdx.x;
+
+    // stage input -> even/odd polyphase arrays (zero history before the stream start)
+    for (int r = tid; r < NX / 2; r += 256) {
+        const long long i0 = x0 + 2 * r;
+        float e = 0.0f, o = 0.0f;
+        if (i0 >= 0 && i0 + 1 < x_end) {
+            const float *p = job.src + (i0 - job.src_base);
+            e = p[0];
+            o = p[1];
+        }
+        xe[r] = e;
+        xo[r] = o;
+    }
+    __syncthreads();
+    for (int j = tid; j < NA_OUT; j += 256) {
+        const float y = hbf_point<HBF_MA>(xe, xo, c_taps_a, j, A_CE, A_CO);
+        if (j & 1)
+            ao[j >> 1] = y;
+        else
+            ae[j >> 1] = y;
+    }
+    __syncthreads();
+    for (int j = tid; j < NB_OUT; j += 256) {
+        const float y = hbf_point<HBF_MB>(ae, ao, c_taps_b, j, B_CE, B_CO);
+        if (j & 1)
+            bo[j >> 1] = y;
+        else
+            be[j >> 1] = y;
+    }
+    __syncthreads();
+    if (tid < nvalid) {
+        const float y = hbf_point<HBF_MC>(be, bo, c_taps_c, tid, C_CE, C_CO);
+        const long long o = mt0 + tid - batch.drain; // drop the first `drain` outputs ever
+        if (o >= 0)
+            job.dst[o - job.dst_base] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// reduce / tail / fill / adcdac
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void reduce_kernel(const RedBatch batch)
+{
+    const RedJob &job = batch.jobs[blockIdx.y];
+    const int n = batch.n;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > n / 2)
+        return;
+    const int km = (n - k) & (n - 1);
+    double acc = 0.0;
+    for (int t = 0; t < job.ntiles; ++t) {
+        const float *p = job.partial + (size_t)t * n;
+        acc += (double)p[k] + (double)p[km];
+    }
+    job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const TailBatch batch)
+{
+    const TailJob &job = batch.jobs[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < job.count; i += gridDim.x * 256)
+        job.dst[i] = job.src[i];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_noise_kernel(float *x, size_t len, uint64_t seed,
+                                                         uint64_t first)
+{
+    const float scale = 3.4641016151377544f; // sqrt(12), src/psd.rs:605
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
+        const uint64_t r = splitmix64(seed + first + i);
+        const float u = (float)(r >> 40) * 5.9604644775390625e-08f; // 2^-24
+        x[i] = (u - 0.5f) * scale;
+    }
+}
+
+// AdcDac payload (src/de/data.rs:13): per batch [[[u8;2];8];4], channel-major.
+// One thread per (frame, batch, channel): 16 payload bytes -> 8 samples.
+__global__ __launch_bounds__(256) void adcdac_kernel(const uint8_t *__restrict__ frames,
+                                                     size_t frame_size, size_t n_frames, int batches,
+                                                     float *d0, float *d1, float *d2, float *d3)
+{
+    const float lsb = 4.096f * 2.5f / 32768.0f; // src/de/data.rs:28-35
+    const size_t total = n_frames * (size_t)batches * 4;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int ch = (int)(g & 3);
+        const size_t fb = g >> 2;
+        const size_t f = fb / (size_t)batches, b = fb % (size_t)batches;
+        const uint8_t *p = frames + f * frame_size + 8 + (b * 4 + (size_t)ch) * 16;
+        float *dst = (ch == 0 ? d0 : ch == 1 ? d1 : ch == 2 ? d2 : d3) + fb * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint16_t raw = (uint16_t)p[2 * i] | ((uint16_t)p[2 * i + 1] << 8); // i16::from_le_bytes
+            if (ch >= 2)
+                raw = (uint16_t)(raw + 0x8000u); // wrapping_add(i16::MIN) :64,:75
+            dst[i] = (float)(int16_t)raw * lsb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+
+int welch_segments_per_tile(int n)
+{
+    switch (n) {
+#define PSDK_CASE(NN) \
+    case NN:          \
+        return WelchCfg<NN>::SPT;
+        PSDK_CASE(16)
+        PSDK_CASE(32)
+        PSDK_CASE(64)
+        PSDK_CASE(128)
+        PSDK_CASE(256)
+        PSDK_CASE(512)
+        PSDK_CASE(1024)
+        PSDK_CASE(2048)
+        PSDK_CASE(4096)
+        PSDK_CASE(8192)
+        PSDK_CASE(16384)
+#undef PSDK_CASE
+    default:
+        return 0;
+    }
+}
+
+bool welch_supported(int n) { return welch_segments_per_tile(n) != 0; }
+
+hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s)
+{
+    if (b.ntiles <= 0)
+        return hipSuccess;
+    switch (n) {
+#define PSDK_CASE(NN)                                                                           \
+    case NN:                                                                                    \
+        hipLaunchKernelGGL(welch_kernel<NN>, dim3(b.ntiles), dim3(WelchCfg<NN>::BLOCK), 0, s, b, \
+                           win, tw);                                                            \
+        break;
+        PSDK_CASE(16)
+        PSDK_CASE(32)
+        PSDK_CASE(64)
+        PSDK_CASE(128)
+        PSDK_CASE(256)
+        PSDK_CASE(512)
+        PSDK_CASE(1024)
+        PSDK_CASE(2048)
+        PSDK_CASE(4096)
+        PSDK_CASE(8192)
+        PSDK_CASE(16384)
+#undef PSDK_CASE
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dec(const DecBatch &b, hipStream_t s)
+{
+    if (b.ntiles <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(hbf_dec8_kernel, dim3(b.ntiles), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(const RedBatch &b, hipStream_t s)
+{
+    if (b.njobs <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(reduce_kernel, dim3((b.n / 2 + 1 + 255) / 256, b.njobs), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail(const TailBatch &b, hipStream_t s)
+{
+    if (b.njobs <= 0)
+        return hipSuccess;
+    int mx = 0;
+    for (int i = 0; i < b.njobs; ++i)
+        mx = b.jobs[i].count > mx ? b.jobs[i].count : mx;
+    if (mx == 0)
+        return hipSuccess;
+    const int gx = (mx + 255) / 256 > 64 ? 64 : (mx + 255) / 256;
+    hipLaunchKernelGGL(tail_kernel, dim3(gx, b.njobs), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s)
+{
+    if (len == 0)
+        return hipSuccess;
+    size_t blocks = (len + 255) / 256;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_x, len, seed, first);
+    return hipGetLastError();
+}
+
+hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,
+                         float *dst0, float *dst1, float *dst2, float *dst3, hipStream_t s)
+{
+    const size_t total = n_frames * (size_t)batches * 4;
+    if (total == 0)
+        return hipSuccess;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(adcdac_kernel, dim3((unsigned)blocks), dim3(256), 0, s, frames, frame_size,
+                       n_frames, batches, dst0, dst1, dst2, dst3);
+    return hipGetLastError();
+}
+
+} // namespace psdk

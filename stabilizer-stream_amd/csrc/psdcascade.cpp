@@ -1,0 +1,1410 @@
+// psdcascade.cpp -- host runtime behind include/psdcascade.h.
+//
+// Mirrors PsdCascade<N> (src/psd.rs:399-544) for `n_channels` independent
+// traces on one MI355X: per (channel, stage) it keeps the stream position, the
+// count and a device stream buffer, turns each batch of newly completed
+// segments into kernel jobs (plan.h gives the closed forms of the reference's
+// per-sample loop), and stitches the read-out on the host.
+//
+// There is no CPU compute path: every spectrum comes from the HIP kernels.
+#include "../../include/psdcascade.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "hbf_taps.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace psdk;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    float *p[2] = {nullptr, nullptr}; // ping-pong: the tail is carried to the other buffer
+    int cur = 0;
+    size_t cap = 0;    // floats per buffer
+    uint64_t base = 0; // absolute stream index of p[cur][0]
+    uint64_t end = 0;  // the buffer holds [base, end); == total unless a zero-copy span is pending
+};
+
+struct StageState {
+    uint64_t total = 0; // samples received by this stage (absolute end of its stream)
+    uint64_t segs = 0;  // segments issued (J)
+    uint64_t dec = 0;   // samples handed to the decimator (P)
+    uint32_t count = 0; // PsdStage::count (src/psd.rs:128)
+    DevBuf buf;
+    float *spectrum = nullptr; // device, n floats (first n/2+1 used, src/psd.rs:127)
+};
+
+struct DeviceSpan {
+    const float *d_x = nullptr;
+    uint64_t first = 0; // absolute index of d_x[0] in the stage-0 stream
+    size_t len = 0;
+};
+
+struct Channel {
+    std::vector<StageState> st;
+    float *stage_host[2] = {nullptr, nullptr}; // pinned staging (host-fed samples)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool ev_pending[2] = {false, false};
+    int cur_stage = 0;
+    size_t fill = 0;
+    bool submitted = false; // device holds samples that advance() has not looked at yet
+    bool has_span = false;  // zero-copy span registered but not enqueued
+    DeviceSpan span;
+};
+
+struct ProfEvents {
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct psdc_handle {
+    uint32_t n = 0;
+    int window_kind = PSDC_WINDOW_HANN;
+    Geometry geo;
+    float nenbw = 1.5f, power = 0.25f;
+    uint32_t n_channels = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float *d_win = nullptr;
+    cf *d_tw = nullptr;
+    int detrend = PSDC_DETREND_NONE;
+    uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
+    std::vector<Channel> ch;
+    float *d_partial = nullptr;
+    size_t partial_cap = 0; // floats
+    uint8_t *d_frames = nullptr;
+    size_t frames_cap = 0;
+    uint8_t *h_frames = nullptr; // pinned
+    size_t h_frames_cap = 0;
+    size_t quantum = (size_t)1 << 22;
+    bool profile = false;
+    std::vector<ProfEvents> prof_pending;
+    psdc_profile prof{};
+    std::string err;
+};
+
+namespace {
+
+int fail(psdc_handle *h, int code, const std::string &msg)
+{
+    if (h)
+        h->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, PSDC_ERR_DEVICE,                                                      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+struct WindowConsts {
+    float nenbw, power;
+    uint32_t overlap;
+};
+
+bool window_consts(uint32_t n, int kind, WindowConsts *w)
+{
+    if (kind == PSDC_WINDOW_RECTANGULAR) { // src/psd.rs:24-32
+        *w = {1.0f, 1.0f, 0};
+        return true;
+    }
+    if (kind == PSDC_WINDOW_HANN) { // src/psd.rs:49-54
+        *w = {1.5f, 0.25f, n / 2};
+        return true;
+    }
+    return false;
+}
+
+bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1)) == 0; }
+
+// PsdStage::gain (src/psd.rs:279-283): u32 multiply, then two f32 multiplies
+float stage_gain(uint32_t n, uint32_t count, float nenbw, float power)
+{
+    const uint32_t m = n / 2u * count; // wraps like release-mode Rust
+    return (float)m * nenbw * power;
+}
+
+uint32_t cur_stage_avg(const psdc_handle *h, size_t i) { return stage_avg(h->avg_limit, h->avg_count, (unsigned)i); }
+
+// lowest absolute index a stage must keep for its next batch: the start of the
+// next segment and the decimator history
+uint64_t keep_from(const Geometry &g, const StageState &s)
+{
+    if (s.segs == 0)
+        return 0;
+    const uint64_t back = std::max<uint64_t>(g.overlap, HBF_HALO);
+    return s.dec > back ? s.dec - back : 0;
+}
+
+int free_stage(psdc_handle *h, StageState &s)
+{
+    for (int i = 0; i < 2; ++i)
+        if (s.buf.p[i]) {
+            HIPCHK(h, hipFree(s.buf.p[i]));
+            s.buf.p[i] = nullptr;
+        }
+    if (s.spectrum) {
+        HIPCHK(h, hipFree(s.spectrum));
+        s.spectrum = nullptr;
+    }
+    return PSDC_OK;
+}
+
+int add_stage(psdc_handle *h, Channel &c)
+{
+    StageState s;
+    HIPCHK(h, hipMalloc(&s.spectrum, sizeof(float) * h->n));
+    HIPCHK(h, hipMemsetAsync(s.spectrum, 0, sizeof(float) * h->n, h->stream));
+    c.st.push_back(s);
+    return PSDC_OK;
+}
+
+// make room for absolute indices [base, new_end) in the current buffer
+int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
+{
+    const size_t need = (size_t)(new_end - s.buf.base);
+    if (need <= s.buf.cap)
+        return PSDC_OK;
+    const size_t min_cap = (size_t)4 * (h->n + HBF_HALO) + 64;
+    size_t cap = std::max(need + need / 2, min_cap);
+    float *np[2] = {nullptr, nullptr};
+    HIPCHK(h, hipMalloc(&np[0], sizeof(float) * cap));
+    HIPCHK(h, hipMalloc(&np[1], sizeof(float) * cap));
+    const size_t have = (size_t)(s.buf.end - s.buf.base);
+    if (have && s.buf.p[s.buf.cur])
+        HIPCHK(h, hipMemcpyAsync(np[0], s.buf.p[s.buf.cur], sizeof(float) * have,
+                                 hipMemcpyDeviceToDevice, h->stream));
+    if (s.buf.p[0] || s.buf.p[1]) {
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // rare: only while buffers grow
+        for (int i = 0; i < 2; ++i)
+            if (s.buf.p[i])
+                HIPCHK(h, hipFree(s.buf.p[i]));
+    }
+    s.buf.p[0] = np[0];
+    s.buf.p[1] = np[1];
+    s.buf.cur = 0;
+    s.buf.cap = cap;
+    return PSDC_OK;
+}
+
+int ensure_partial(psdc_handle *h, size_t floats)
+{
+    if (floats <= h->partial_cap)
+        return PSDC_OK;
+    if (h->d_partial) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->d_partial));
+        h->d_partial = nullptr;
+    }
+    const size_t cap = floats + floats / 2;
+    HIPCHK(h, hipMalloc(&h->d_partial, sizeof(float) * cap));
+    h->partial_cap = cap;
+    return PSDC_OK;
+}
+
+struct Span { // one contiguous source of a (channel, stage) batch
+    const float *src;
+    uint64_t src_base;
+    uint64_t seg_a, seg_b; // segments [seg_a, seg_b)
+    uint64_t m_a, m_b;     // decimator outputs [m_a, m_b)
+};
+
+struct Work {
+    uint32_t c, k;
+    uint64_t j_old, j_new, p_old, p_new;
+    EwmaPlan ew;
+    Span spans[2];
+    int nspans = 0;
+};
+
+int collect_profile(psdc_handle *h)
+{
+    for (auto &e : h->prof_pending) {
+        HIPCHK(h, hipEventSynchronize(e.b));
+        float ms = 0.0f;
+        HIPCHK(h, hipEventElapsedTime(&ms, e.a, e.b));
+        h->prof.kernel_ms += (double)ms;
+        HIPCHK(h, hipEventDestroy(e.a));
+        HIPCHK(h, hipEventDestroy(e.b));
+    }
+    h->prof_pending.clear();
+    return PSDC_OK;
+}
+
+// Issue every complete segment of every stage of every channel.
+int advance(psdc_handle *h)
+{
+    const Geometry &g = h->geo;
+    const int spt = welch_segments_per_tile((int)h->n);
+    const uint64_t seam = (uint64_t)h->n + HBF_HALO;
+
+    // zero-copy spans: copy the seam (the part that completes segments begun in
+    // the carried tail) behind the tail; the bulk is read in place
+    for (auto &c : h->ch) {
+        if (!c.has_span)
+            continue;
+        StageState &s0 = c.st[0];
+        const uint64_t cp = std::min<uint64_t>(seam, c.span.len);
+        int rc = ensure_room(h, s0, c.span.first + cp);
+        if (rc)
+            return rc;
+        HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (c.span.first - s0.buf.base), c.span.d_x,
+                                 sizeof(float) * cp, hipMemcpyDeviceToDevice, h->stream));
+        s0.buf.end = c.span.first + cp;
+    }
+
+    std::vector<Work> touched;
+    for (uint32_t k = 0;; ++k) {
+        std::vector<Work> works;
+        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+            Channel &c = h->ch[ci];
+            if (c.st.size() <= k)
+                continue;
+            StageState &s = c.st[k];
+            const uint64_t j_new = segments_for(g, s.total);
+            if (j_new == s.segs)
+                continue;
+            Work w;
+            w.c = ci;
+            w.k = k;
+            w.j_old = s.segs;
+            w.j_new = j_new;
+            w.p_old = s.dec;
+            w.p_new = decimated_prefix(g, j_new);
+            w.ew = plan_ewma(s.count, cur_stage_avg(h, k), j_new - s.segs);
+            const uint64_t m_old = w.p_old >> 3, m_new = w.p_new >> 3;
+            if (k == 0 && c.has_span) {
+                const uint64_t first = c.span.first;
+                const uint64_t j_split =
+                    std::min<uint64_t>(j_new, std::max<uint64_t>(w.j_old, (first + g.hop - 1) / g.hop));
+                const uint64_t m_split =
+                    std::min<uint64_t>(m_new, std::max<uint64_t>(m_old, (first + HBF_HALO + 7) / 8));
+                if (j_split > w.j_old || m_split > m_old)
+                    w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_split, m_old, m_split};
+                if (j_new > j_split || m_new > m_split)
+                    w.spans[w.nspans++] = {c.span.d_x, first, j_split, j_new, m_split, m_new};
+            } else {
+                w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new};
+            }
+            works.push_back(w);
+        }
+        if (works.empty())
+            break;
+
+        // next-stage streams and partial slab
+        size_t tiles_total = 0;
+        for (auto &w : works) {
+            Channel &c = h->ch[w.c];
+            const uint64_t t_next = emitted_for(g, w.p_new);
+            if (t_next > 0) {
+                if (c.st.size() <= (size_t)w.k + 1) {
+                    int rc = add_stage(h, c);
+                    if (rc)
+                        return rc;
+                }
+                int rc = ensure_room(h, c.st[w.k + 1], t_next);
+                if (rc)
+                    return rc;
+            }
+            for (int i = 0; i < w.nspans; ++i)
+                tiles_total += (size_t)((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
+        }
+        int rc = ensure_partial(h, tiles_total * h->n);
+        if (rc)
+            return rc;
+
+        // welch + reduce, at most MAX_JOBS spans per launch
+        size_t slab = 0; // floats used in d_partial
+        size_t wi = 0;
+        while (wi < works.size()) {
+            WelchBatch wb{};
+            RedBatch rb{};
+            wb.hop = (int)g.hop;
+            wb.detrend = h->detrend;
+            rb.n = (int)h->n;
+            uint64_t samples = 0, samples0 = 0;
+            while (wi < works.size() && wb.njobs + works[wi].nspans <= MAX_JOBS) {
+                const Work &w = works[wi];
+                StageState &s = h->ch[w.c].st[w.k];
+                RedJob rj{};
+                rj.partial = h->d_partial + slab;
+                rj.spectrum = s.spectrum;
+                rj.g_total = (float)w.ew.g_total;
+                for (int i = 0; i < w.nspans; ++i) {
+                    const Span &sp = w.spans[i];
+                    const uint64_t nseg = sp.seg_b - sp.seg_a;
+                    if (nseg == 0)
+                        continue;
+                    SegJob &sj = wb.jobs[wb.njobs++];
+                    sj.src = sp.src;
+                    sj.src_base = (long long)sp.src_base;
+                    sj.seg0 = (long long)sp.seg_a;
+                    sj.partial = h->d_partial + slab;
+                    sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                                      : -std::numeric_limits<double>::infinity();
+                    sj.nseg = (int)nseg;
+                    sj.tile_begin = wb.ntiles;
+                    sj.step0 = (int)(sp.seg_a - w.j_old) + 1;
+                    sj.nb = (int)w.ew.nb;
+                    sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+                    sj.ewma = w.ew.ewma ? 1 : 0;
+                    const int nt = (int)((nseg + spt - 1) / spt);
+                    wb.ntiles += nt;
+                    rj.ntiles += nt;
+                    slab += (size_t)nt * h->n;
+                }
+                rb.jobs[rb.njobs++] = rj;
+                const uint64_t ns = w.p_new - w.p_old;
+                samples += ns;
+                if (w.k == 0)
+                    samples0 += ns;
+                ++wi;
+            }
+            ProfEvents pe{};
+            if (h->profile) {
+                HIPCHK(h, hipEventCreate(&pe.a));
+                HIPCHK(h, hipEventCreate(&pe.b));
+                HIPCHK(h, hipEventRecord(pe.a, h->stream));
+            }
+            HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
+            if (h->profile) {
+                HIPCHK(h, hipEventRecord(pe.b, h->stream));
+                h->prof_pending.push_back(pe);
+                h->prof.launches += 1;
+                h->prof.samples += samples;
+                h->prof.stage0_samples += samples0;
+            }
+            HIPCHK(h, launch_reduce(rb, h->stream));
+        }
+
+        // decimator
+        wi = 0;
+        size_t span_i = 0;
+        while (wi < works.size()) {
+            DecBatch db{};
+            db.drain = (int)g.drain;
+            while (wi < works.size() && db.njobs < MAX_JOBS) {
+                const Work &w = works[wi];
+                Channel &c = h->ch[w.c];
+                bool advanced = true;
+                for (; span_i < (size_t)w.nspans; ++span_i) {
+                    if (db.njobs >= MAX_JOBS) {
+                        advanced = false;
+                        break;
+                    }
+                    const Span &sp = w.spans[span_i];
+                    const uint64_t nout = sp.m_b - sp.m_a;
+                    if (nout == 0 || sp.m_b <= g.drain)
+                        continue; // nothing reaches the next stage yet
+                    StageState &nx = c.st[w.k + 1];
+                    DecJob &dj = db.jobs[db.njobs++];
+                    dj.src = sp.src;
+                    dj.src_base = (long long)sp.src_base;
+                    dj.m0 = (long long)sp.m_a;
+                    dj.dst = nx.buf.p[nx.buf.cur];
+                    dj.dst_base = (long long)nx.buf.base;
+                    dj.nout = (int)nout;
+                    dj.tile_begin = db.ntiles;
+                    db.ntiles += (int)((nout + DEC_TILE - 1) / DEC_TILE);
+                }
+                if (!advanced)
+                    break;
+                span_i = 0;
+                ++wi;
+            }
+            HIPCHK(h, launch_dec(db, h->stream));
+        }
+
+        // bookkeeping
+        for (auto &w : works) {
+            Channel &c = h->ch[w.c];
+            StageState &s = c.st[w.k];
+            s.count = count_after(s.count, cur_stage_avg(h, w.k), w.j_new - w.j_old);
+            s.segs = w.j_new;
+            s.dec = w.p_new;
+            const uint64_t t_next = emitted_for(g, w.p_new);
+            if (t_next > 0) {
+                c.st[w.k + 1].total = t_next;
+                c.st[w.k + 1].buf.end = t_next;
+            }
+            touched.push_back(w);
+        }
+    }
+
+    // carry the tails into the other buffer of each touched stream
+    {
+        TailBatch tb{};
+        auto flush_tb = [&]() -> int {
+            if (tb.njobs) {
+                HIPCHK(h, launch_tail(tb, h->stream));
+                tb = TailBatch{};
+            }
+            return PSDC_OK;
+        };
+        for (auto &w : touched) {
+            Channel &c = h->ch[w.c];
+            StageState &s = c.st[w.k];
+            const uint64_t kf = keep_from(g, s);
+            if (kf == s.buf.base && s.buf.end == s.total)
+                continue;
+            const uint64_t cnt = s.total - kf;
+            const float *src;
+            if (w.k == 0 && c.has_span && kf >= c.span.first)
+                src = c.span.d_x + (kf - c.span.first);
+            else
+                src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
+            if (cnt > s.buf.cap)
+                return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
+            const int other = s.buf.cur ^ 1;
+            if (cnt) {
+                if (tb.njobs == MAX_JOBS) {
+                    int rc = flush_tb();
+                    if (rc)
+                        return rc;
+                }
+                tb.jobs[tb.njobs++] = {src, s.buf.p[other], (int)cnt};
+            }
+            s.buf.cur = other;
+            s.buf.base = kf;
+            s.buf.end = s.total;
+        }
+        int rc = flush_tb();
+        if (rc)
+            return rc;
+    }
+    for (auto &c : h->ch) {
+        // a span is at least 4*(n + halo) long, so it always completes segments
+        // and its tail was carried out of d_x above
+        if (c.has_span && c.st[0].buf.end != c.st[0].total)
+            return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
+        c.has_span = false;
+        c.submitted = false;
+    }
+    return PSDC_OK;
+}
+
+int submit_host(psdc_handle *h, Channel &c)
+{
+    if (c.fill == 0)
+        return PSDC_OK;
+    if (c.st.empty()) {
+        int rc = add_stage(h, c);
+        if (rc)
+            return rc;
+    }
+    StageState &s0 = c.st[0];
+    int rc = ensure_room(h, s0, s0.total + c.fill);
+    if (rc)
+        return rc;
+    const int b = c.cur_stage;
+    HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base), c.stage_host[b],
+                             sizeof(float) * c.fill, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(c.stage_ev[b], h->stream));
+    c.ev_pending[b] = true;
+    s0.total += c.fill;
+    s0.buf.end = s0.total;
+    c.fill = 0;
+    c.submitted = true;
+    c.cur_stage = b ^ 1;
+    if (c.ev_pending[c.cur_stage]) {
+        HIPCHK(h, hipEventSynchronize(c.stage_ev[c.cur_stage]));
+        c.ev_pending[c.cur_stage] = false;
+    }
+    return PSDC_OK;
+}
+
+int ensure_staging(psdc_handle *h, Channel &c)
+{
+    if (c.stage_host[0])
+        return PSDC_OK;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&c.stage_host[i]), sizeof(float) * h->quantum,
+                                hipHostMallocDefault));
+        HIPCHK(h, hipEventCreateWithFlags(&c.stage_ev[i], hipEventDisableTiming));
+    }
+    return PSDC_OK;
+}
+
+int free_staging(psdc_handle *h, Channel &c)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (c.stage_host[i]) {
+            HIPCHK(h, hipHostFree(c.stage_host[i]));
+            c.stage_host[i] = nullptr;
+        }
+        if (c.stage_ev[i]) {
+            HIPCHK(h, hipEventDestroy(c.stage_ev[i]));
+            c.stage_ev[i] = nullptr;
+        }
+        c.ev_pending[i] = false;
+    }
+    return PSDC_OK;
+}
+
+int flush_all(psdc_handle *h)
+{
+    for (auto &c : h->ch) {
+        int rc = submit_host(h, c);
+        if (rc)
+            return rc;
+    }
+    return advance(h);
+}
+
+int flush_sync(psdc_handle *h)
+{
+    int rc = flush_all(h);
+    if (rc)
+        return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PSDC_OK;
+}
+
+int check_channel(psdc_handle *h, uint32_t channel)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    if (channel >= h->n_channels)
+        return fail(h, PSDC_ERR_ARG, "channel out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    return PSDC_OK;
+}
+
+int stitch_impl(uint32_t n, float nenbw, float power, uint32_t overlap, uint32_t n_stages,
+                const uint32_t *counts, const uint32_t *avgs, const uint64_t *pendings,
+                const float *spectra, int keep_overlap, uint32_t min_count, int keep_transition_band,
+                float *psd_out, size_t psd_cap, size_t *psd_len, psdc_break *breaks,
+                size_t breaks_cap, size_t *n_breaks)
+{
+    // PsdCascade::psd (src/psd.rs:479-543)
+    const size_t bins = n / 2 + 1;
+    size_t plen = 0, nb = 0;
+    uint64_t decimation = 1ull << (3 * n_stages); // :482
+    size_t end = 0;
+    bool overflow = false;
+    for (int si = (int)n_stages - 1; si >= 0; --si) { // .rev() :484
+        decimation >>= 3;
+        const size_t start = keep_overlap ? 0 : ((end + 7) >> 3);                     // :490-495
+        end = (decimation > 1 && !keep_transition_band) ? (size_t)(2 * n / 5) : bins; // :496-501
+        const bool include = counts[si] >= min_count;                                 // :502
+        if (breaks) {
+            if (nb < breaks_cap) {
+                psdc_break &b = breaks[nb];
+                b.start = plen;
+                b.include = include ? 1u : 0u;
+                b.count = counts[si];
+                b.avg = avgs[si];
+                b._pad = 0;
+                b.bins_start = start;
+                b.bins_end = end;
+                b.fft_size = n;
+                b.decimation = decimation;
+                const uint32_t cm1 = counts[si] ? counts[si] - 1 : 0; // saturating_sub(1)
+                b.processed = (uint64_t)n * counts[si] - (uint64_t)overlap * cm1; // :511-512
+                b.pending = pendings[si];
+            } else {
+                overflow = true;
+            }
+        }
+        ++nb;
+        if (include) { // :515-517
+            const float gsc = 1.0f / (stage_gain(n, counts[si], nenbw, power) * (float)decimation);
+            for (size_t k = start; k < end; ++k) {
+                if (psd_out) {
+                    if (plen < psd_cap)
+                        psd_out[plen] = spectra[(size_t)si * bins + k] * gsc;
+                    else
+                        overflow = true;
+                }
+                ++plen;
+            }
+        } else {
+            end = start; // :518-520
+        }
+    }
+    if (psd_len)
+        *psd_len = plen;
+    if (n_breaks)
+        *n_breaks = nb;
+    return overflow ? PSDC_ERR_CAPACITY : PSDC_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+int psdc_abi_version(void) { return PSDC_ABI_VERSION; }
+
+const char *psdc_last_error(const psdc_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device)
+{
+    WindowConsts wc{};
+    if (!valid_n(n) || !welch_supported((int)n)) {
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 16384]");
+        return nullptr;
+    }
+    if (!window_consts(n, window_kind, &wc)) {
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: unknown window kind");
+        return nullptr;
+    }
+    if ((n - wc.overlap) % 8 != 0) { // src/psd.rs:246-247
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: (n - overlap) must be a multiple of 8");
+        return nullptr;
+    }
+    if (n_channels == 0 || n_channels > 4096) {
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n_channels out of range");
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(nullptr, PSDC_ERR_DEVICE,
+             std::string("psdc_create: no HIP device (there is no CPU fallback): ") +
+                 (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: device index out of range");
+        return nullptr;
+    }
+    psdc_handle *h = new (std::nothrow) psdc_handle();
+    if (!h) {
+        fail(nullptr, PSDC_ERR_NOMEM, "psdc_create: out of memory");
+        return nullptr;
+    }
+    h->n = n;
+    h->window_kind = window_kind;
+    h->geo.n = n;
+    h->geo.overlap = wc.overlap;
+    h->geo.hop = n - wc.overlap;
+    h->geo.drain = (uint32_t)HBF_DRAIN;
+    h->nenbw = wc.nenbw;
+    h->power = wc.power;
+    h->n_channels = n_channels;
+    h->device = device;
+    h->ch.resize(n_channels);
+
+    // window table exactly as the reference builds it (src/psd.rs:44-48), twiddles in f64
+    std::vector<float> win(n);
+    if (window_kind == PSDC_WINDOW_HANN) {
+        const float df = 3.14159265358979323846f / (float)n;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float s = sinf(df * (float)i);
+            win[i] = s * s;
+        }
+    } else {
+        for (uint32_t i = 0; i < n; ++i)
+            win[i] = 1.0f;
+    }
+    std::vector<cf> tw(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double a = -2.0 * M_PI * (double)i / (double)n;
+        tw[i] = {(float)cos(a), (float)sin(a)};
+    }
+    auto dev_fail = [&](hipError_t err, const char *what) -> psdc_handle * {
+        fail(nullptr, PSDC_ERR_DEVICE, std::string("psdc_create: ") + what + ": " + hipGetErrorString(err));
+        psdc_destroy(h);
+        return nullptr;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return dev_fail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+        return dev_fail(e, "hipStreamCreate");
+    if ((e = hipMalloc(&h->d_win, sizeof(float) * n)) != hipSuccess)
+        return dev_fail(e, "hipMalloc(win)");
+    if ((e = hipMalloc(&h->d_tw, sizeof(cf) * n)) != hipSuccess)
+        return dev_fail(e, "hipMalloc(tw)");
+    if ((e = hipMemcpy(h->d_win, win.data(), sizeof(float) * n, hipMemcpyHostToDevice)) != hipSuccess)
+        return dev_fail(e, "hipMemcpy(win)");
+    if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
+        return dev_fail(e, "hipMemcpy(tw)");
+    return h;
+}
+
+void psdc_destroy(psdc_handle *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    (void)collect_profile(h);
+    for (auto &c : h->ch) {
+        for (auto &s : c.st)
+            (void)free_stage(h, s);
+        (void)free_staging(h, c);
+    }
+    if (h->d_partial)
+        (void)hipFree(h->d_partial);
+    if (h->d_frames)
+        (void)hipFree(h->d_frames);
+    if (h->h_frames)
+        (void)hipHostFree(h->h_frames);
+    if (h->d_win)
+        (void)hipFree(h->d_win);
+    if (h->d_tw)
+        (void)hipFree(h->d_tw);
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int psdc_reset(psdc_handle *h)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto &c : h->ch) {
+        for (auto &s : c.st) {
+            int rc = free_stage(h, s);
+            if (rc)
+                return rc;
+        }
+        c.st.clear();
+        c.fill = 0;
+        c.submitted = false;
+        c.has_span = false;
+    }
+    return PSDC_OK;
+}
+
+int psdc_configure(psdc_handle *h, int option, int64_t value)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    switch (option) {
+    case PSDC_OPT_QUANTUM: {
+        if (value < 1 || value > ((int64_t)1 << 30))
+            return fail(h, PSDC_ERR_ARG, "quantum out of range");
+        int rc = flush_sync(h);
+        if (rc)
+            return rc;
+        for (auto &c : h->ch) {
+            rc = free_staging(h, c);
+            if (rc)
+                return rc;
+        }
+        h->quantum = (size_t)value;
+        return PSDC_OK;
+    }
+    case PSDC_OPT_PROFILE:
+        h->profile = value != 0;
+        return PSDC_OK;
+    default:
+        return fail(h, PSDC_ERR_ARG, "unknown option");
+    }
+}
+
+int psdc_set_detrend(psdc_handle *h, int kind)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    if (kind == PSDC_DETREND_LINEAR)
+        return fail(h, PSDC_ERR_UNIMPLEMENTED, "Detrend::Linear is unimplemented (src/psd.rs:110)");
+    if (kind < 0 || kind > PSDC_DETREND_LINEAR)
+        return fail(h, PSDC_ERR_ARG, "unknown detrend kind");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = flush_all(h); // segments completed so far keep the old setting
+    if (rc)
+        return rc;
+    h->detrend = kind;
+    return PSDC_OK;
+}
+
+int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = flush_all(h);
+    if (rc)
+        return rc;
+    h->avg_limit = limit;
+    h->avg_count = count;
+    return PSDC_OK;
+}
+
+int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    if (len == 0)
+        return PSDC_OK; // x.chunks() yields nothing: no stage is created (src/psd.rs:459)
+    if (!x)
+        return fail(h, PSDC_ERR_ARG, "null input");
+    Channel &c = h->ch[channel];
+    if (c.has_span) { // keep the stream in order behind a pending zero-copy span
+        rc = advance(h);
+        if (rc)
+            return rc;
+    }
+    rc = ensure_staging(h, c);
+    if (rc)
+        return rc;
+    if (c.st.empty()) {
+        rc = add_stage(h, c);
+        if (rc)
+            return rc;
+    }
+    while (len > 0) {
+        const size_t take = std::min(len, h->quantum - c.fill);
+        memcpy(c.stage_host[c.cur_stage] + c.fill, x, sizeof(float) * take);
+        c.fill += take;
+        x += take;
+        len -= take;
+        if (c.fill == h->quantum) {
+            if (c.submitted) { // a full round of channels is on the device: run it as one batch
+                rc = advance(h);
+                if (rc)
+                    return rc;
+            }
+            rc = submit_host(h, c);
+            if (rc)
+                return rc;
+            if (h->n_channels == 1) {
+                rc = advance(h);
+                if (rc)
+                    return rc;
+            }
+        }
+    }
+    return PSDC_OK;
+}
+
+int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size_t len)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    if (len == 0)
+        return PSDC_OK;
+    if (!d_x)
+        return fail(h, PSDC_ERR_ARG, "null input");
+    Channel &c = h->ch[channel];
+    if (c.has_span || c.submitted) {
+        rc = advance(h);
+        if (rc)
+            return rc;
+    }
+    rc = submit_host(h, c); // host-fed samples staged earlier come first
+    if (rc)
+        return rc;
+    if (c.st.empty()) {
+        rc = add_stage(h, c);
+        if (rc)
+            return rc;
+    }
+    StageState &s0 = c.st[0];
+    if (len < (size_t)4 * (h->n + HBF_HALO)) {
+        // short span: append a copy, like host-fed samples
+        rc = ensure_room(h, s0, s0.total + len);
+        if (rc)
+            return rc;
+        HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base), d_x,
+                                 sizeof(float) * len, hipMemcpyDeviceToDevice, h->stream));
+        s0.total += len;
+        s0.buf.end = s0.total;
+        c.submitted = true;
+    } else {
+        c.span.d_x = d_x;
+        c.span.first = s0.total;
+        c.span.len = len;
+        c.has_span = true;
+        s0.total += len;
+    }
+    if (h->n_channels == 1)
+        return advance(h);
+    return PSDC_OK;
+}
+
+int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
+                               size_t n_frames, size_t *n_ok)
+{
+    if (n_ok)
+        *n_ok = 0;
+    int rc = check_channel(h, 0);
+    if (rc)
+        return rc;
+    if (h->n_channels < 4)
+        return fail(h, PSDC_ERR_ARG, "AdcDac frames carry four traces: need n_channels >= 4");
+    if (n_frames == 0)
+        return PSDC_OK;
+    if (!frames)
+        return fail(h, PSDC_ERR_ARG, "null input");
+    if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
+        return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
+    // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25)
+    size_t good = 0;
+    int bad = PSDC_OK;
+    const size_t payload = frame_size - 8;
+    const int batches = (int)(payload / 64);
+    for (; good < n_frames; ++good) {
+        const uint8_t *f = frames + good * frame_size;
+        if (f[0] != 0x7b || f[1] != 0x05) {
+            bad = PSDC_ERR_FRAME_HEADER;
+            break;
+        }
+        if (f[2] < 1 || f[2] > 4) {
+            bad = PSDC_ERR_FRAME_FORMAT;
+            break;
+        }
+        if (f[2] != 1) { // Fls / ThermostatEem / Mpll: not AdcDac
+            bad = PSDC_ERR_FRAME_FORMAT;
+            break;
+        }
+        if (payload % 64 != 0 || (int)f[3] != batches) {
+            bad = PSDC_ERR_FRAME_SIZE;
+            break;
+        }
+    }
+    if (good > 0 && batches > 0) {
+        // order behind anything pending on these channels
+        bool pend = false;
+        for (int ci = 0; ci < 4; ++ci)
+            pend = pend || h->ch[ci].has_span || h->ch[ci].submitted || h->ch[ci].fill;
+        if (pend) {
+            rc = flush_all(h);
+            if (rc)
+                return rc;
+        }
+        const size_t bytes = good * frame_size;
+        if (bytes > h->frames_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->d_frames)
+                HIPCHK(h, hipFree(h->d_frames));
+            if (h->h_frames)
+                HIPCHK(h, hipHostFree(h->h_frames));
+            h->d_frames = nullptr;
+            h->h_frames = nullptr;
+            HIPCHK(h, hipMalloc(&h->d_frames, bytes + bytes / 2));
+            HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_frames), bytes + bytes / 2,
+                                    hipHostMallocDefault));
+            h->frames_cap = bytes + bytes / 2;
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->stream)); // pinned bounce buffer is reused
+        }
+        memcpy(h->h_frames, frames, bytes);
+        HIPCHK(h, hipMemcpyAsync(h->d_frames, h->h_frames, bytes, hipMemcpyHostToDevice, h->stream));
+        const size_t per_ch = good * (size_t)batches * 8;
+        float *dst[4];
+        for (int ci = 0; ci < 4; ++ci) {
+            Channel &c = h->ch[ci];
+            if (c.st.empty()) {
+                rc = add_stage(h, c);
+                if (rc)
+                    return rc;
+            }
+            StageState &s0 = c.st[0];
+            rc = ensure_room(h, s0, s0.total + per_ch);
+            if (rc)
+                return rc;
+            dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
+        }
+        HIPCHK(h, launch_adcdac(h->d_frames, frame_size, good, batches, dst[0], dst[1], dst[2], dst[3],
+                                h->stream));
+        for (int ci = 0; ci < 4; ++ci) {
+            h->ch[ci].st[0].total += per_ch;
+            h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
+            h->ch[ci].submitted = true;
+        }
+        rc = advance(h);
+        if (rc)
+            return rc;
+    }
+    if (n_ok)
+        *n_ok = good;
+    if (bad != PSDC_OK)
+        return fail(h, bad,
+                    bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
+                    : bad == PSDC_ERR_FRAME_FORMAT ? "Unknown or non-AdcDac format ID"
+                                                   : "Payload size");
+    return PSDC_OK;
+}
+
+int psdc_flush(psdc_handle *h)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    return flush_all(h);
+}
+
+int psdc_sync(psdc_handle *h)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    return flush_sync(h);
+}
+
+int psdc_num_stages(psdc_handle *h, uint32_t channel)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    rc = flush_all(h);
+    if (rc)
+        return rc;
+    return (int)h->ch[channel].st.size();
+}
+
+int psdc_stage_info(psdc_handle *h, uint32_t channel, uint32_t stage, psdc_stage_stat *out)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    if (!out)
+        return fail(h, PSDC_ERR_ARG, "null output");
+    rc = flush_all(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    if (stage >= c.st.size())
+        return fail(h, PSDC_ERR_ARG, "stage out of range");
+    const StageState &s = c.st[stage];
+    out->count = s.count;
+    out->avg = cur_stage_avg(h, stage);
+    out->pending = pending_for(h->geo, s.total);
+    const uint32_t cm1 = s.count ? s.count - 1 : 0;
+    out->processed = (uint64_t)h->n * s.count - (uint64_t)h->geo.overlap * cm1;
+    return PSDC_OK;
+}
+
+int psdc_stage_spectrum(psdc_handle *h, uint32_t channel, uint32_t stage, float *out)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    if (!out)
+        return fail(h, PSDC_ERR_ARG, "null output");
+    rc = flush_sync(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    if (stage >= c.st.size())
+        return fail(h, PSDC_ERR_ARG, "stage out of range");
+    HIPCHK(h, hipMemcpy(out, c.st[stage].spectrum, sizeof(float) * (h->n / 2 + 1), hipMemcpyDeviceToHost));
+    return PSDC_OK;
+}
+
+int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    if (!out)
+        return fail(h, PSDC_ERR_ARG, "null output");
+    rc = flush_all(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    if (stage >= c.st.size())
+        return fail(h, PSDC_ERR_ARG, "stage out of range");
+    *out = stage_gain(h->n, c.st[stage].count, h->nenbw, h->power);
+    return PSDC_OK;
+}
+
+int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out, size_t cap, size_t *len)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    rc = flush_sync(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    if (stage >= c.st.size())
+        return fail(h, PSDC_ERR_ARG, "stage out of range");
+    const StageState &s = c.st[stage];
+    const uint64_t pend = pending_for(h->geo, s.total);
+    if (len)
+        *len = (size_t)pend;
+    if (!out)
+        return PSDC_OK;
+    if (cap < pend)
+        return fail(h, PSDC_ERR_CAPACITY, "output too small");
+    if (pend) {
+        const uint64_t from = s.total - pend;
+        HIPCHK(h, hipMemcpy(out, s.buf.p[s.buf.cur] + (from - s.buf.base), sizeof(float) * pend,
+                            hipMemcpyDeviceToHost));
+    }
+    return PSDC_OK;
+}
+
+int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_count,
+             int keep_transition_band, float *psd_out, size_t psd_cap, size_t *psd_len,
+             psdc_break *breaks, size_t breaks_cap, size_t *n_breaks)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    rc = flush_sync(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    const size_t ns = c.st.size();
+    const size_t bins = h->n / 2 + 1;
+    std::vector<uint32_t> counts(ns), avgs(ns);
+    std::vector<uint64_t> pend(ns);
+    std::vector<float> spectra(psd_out ? ns * bins : 0);
+    for (size_t i = 0; i < ns; ++i) {
+        counts[i] = c.st[i].count;
+        avgs[i] = cur_stage_avg(h, i);
+        pend[i] = pending_for(h->geo, c.st[i].total);
+        if (psd_out)
+            HIPCHK(h, hipMemcpy(spectra.data() + i * bins, c.st[i].spectrum, sizeof(float) * bins,
+                                hipMemcpyDeviceToHost));
+    }
+    rc = stitch_impl(h->n, h->nenbw, h->power, h->geo.overlap, (uint32_t)ns, counts.data(), avgs.data(),
+                     pend.data(), spectra.data(), keep_overlap, min_count, keep_transition_band, psd_out,
+                     psd_cap, psd_len, breaks, breaks_cap, n_breaks);
+    if (rc)
+        return fail(h, rc, "psdc_psd: output too small");
+    return PSDC_OK;
+}
+
+float psdc_rbw(const psdc_handle *h)
+{
+    // (1 << DEPTH) as f32 / (N as f32 * HBF_PASSBAND) (src/psd.rs:427-429)
+    return h ? 8.0f / ((float)h->n * 0.4f) : 0.0f;
+}
+
+psdc_handle *psdc_clone(psdc_handle *h)
+{
+    if (!h) {
+        fail(nullptr, PSDC_ERR_ARG, "null handle");
+        return nullptr;
+    }
+    if (hipSetDevice(h->device) != hipSuccess || flush_sync(h) != PSDC_OK)
+        return nullptr;
+    psdc_handle *o = psdc_create(h->n, h->window_kind, h->n_channels, h->device);
+    if (!o)
+        return nullptr;
+    o->detrend = h->detrend;
+    o->avg_limit = h->avg_limit;
+    o->avg_count = h->avg_count;
+    o->quantum = h->quantum;
+    o->profile = h->profile;
+    auto bad = [&](const char *what) -> psdc_handle * {
+        fail(nullptr, PSDC_ERR_DEVICE, std::string("psdc_clone: ") + what);
+        psdc_destroy(o);
+        return nullptr;
+    };
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        for (const StageState &s : h->ch[ci].st) {
+            if (add_stage(o, o->ch[ci]) != PSDC_OK)
+                return bad("alloc");
+            StageState &d = o->ch[ci].st.back();
+            d.total = s.total;
+            d.segs = s.segs;
+            d.dec = s.dec;
+            d.count = s.count;
+            d.buf.base = s.buf.base;
+            d.buf.end = s.buf.base; // nothing resident yet
+            if (ensure_room(o, d, s.total) != PSDC_OK)
+                return bad("alloc");
+            if (hipMemcpyAsync(d.spectrum, s.spectrum, sizeof(float) * h->n, hipMemcpyDeviceToDevice,
+                               o->stream) != hipSuccess)
+                return bad("copy");
+            const size_t have = (size_t)(s.total - s.buf.base);
+            if (have && hipMemcpyAsync(d.buf.p[d.buf.cur], s.buf.p[s.buf.cur], sizeof(float) * have,
+                                       hipMemcpyDeviceToDevice, o->stream) != hipSuccess)
+                return bad("copy");
+            d.buf.end = s.total;
+        }
+    }
+    if (hipStreamSynchronize(o->stream) != hipSuccess)
+        return bad("sync");
+    return o;
+}
+
+size_t psdc_frequencies(const psdc_break *b, size_t n, float *out, size_t cap)
+{
+    // Break::frequencies (src/psd.rs:315-327)
+    size_t len = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!b[i].include)
+            continue;
+        const float rbw = 1.0f / (float)(b[i].fft_size * b[i].decimation); // :334-336
+        for (uint64_t f = b[i].bins_start; f < b[i].bins_end; ++f) {
+            if (out && len < cap)
+                out[len] = (float)f * rbw;
+            ++len;
+        }
+    }
+    return len;
+}
+
+int psdc_hbf_response_length(int depth)
+{
+    if (depth < 0 || depth > 3)
+        return PSDC_ERR_ARG;
+    return hbf_response_length(depth);
+}
+
+int psdc_stitch(uint32_t n, int window_kind, uint32_t n_stages, const uint32_t *counts,
+                const uint32_t *avgs, const uint64_t *pendings, const float *spectra, int keep_overlap,
+                uint32_t min_count, int keep_transition_band, float *psd_out, size_t psd_cap,
+                size_t *psd_len, psdc_break *breaks, size_t breaks_cap, size_t *n_breaks)
+{
+    WindowConsts wc{};
+    if (n < 2 || !window_consts(n, window_kind, &wc) || n_stages > 20)
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_stitch: bad arguments");
+    if (n_stages && (!counts || !avgs || !pendings || (psd_out && !spectra)))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_stitch: null input");
+    int rc = stitch_impl(n, wc.nenbw, wc.power, wc.overlap, n_stages, counts, avgs, pendings, spectra,
+                         keep_overlap, min_count, keep_transition_band, psd_out, psd_cap, psd_len, breaks,
+                         breaks_cap, n_breaks);
+    if (rc)
+        return fail(nullptr, rc, "psdc_stitch: output too small");
+    return PSDC_OK;
+}
+
+int psdc_plan_counts(uint32_t n, int window_kind, uint64_t total, uint32_t cap, uint64_t *received,
+                     uint64_t *segments, uint64_t *pending)
+{
+    WindowConsts wc{};
+    if (n < 2 || !window_consts(n, window_kind, &wc) || (n - wc.overlap) % 8 != 0)
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_plan_counts: bad arguments");
+    Geometry g;
+    g.n = n;
+    g.overlap = wc.overlap;
+    g.hop = n - wc.overlap;
+    g.drain = (uint32_t)HBF_DRAIN;
+    int k = 0;
+    uint64_t t = total;
+    while (t > 0 && k < 64) {
+        const uint64_t j = segments_for(g, t);
+        if ((uint32_t)k < cap) {
+            if (received)
+                received[k] = t;
+            if (segments)
+                segments[k] = j;
+            if (pending)
+                pending[k] = pending_for(g, t);
+        }
+        ++k;
+        t = emitted_for(g, decimated_prefix(g, j));
+    }
+    return k;
+}
+
+float psdc_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const float *phase_psd,
+                    const float *frequencies, size_t n, float tau)
+{
+    // Var::eval (src/var.rs:26-45); powi = repeated multiplication
+    auto powi = [](float x, int e) {
+        const bool neg = e < 0;
+        unsigned u = (unsigned)(neg ? -e : e);
+        float r = 1.0f, b = x;
+        while (u) {
+            if (u & 1u)
+                r *= b;
+            b *= b;
+            u >>= 1;
+        }
+        return neg ? 1.0f / r : r;
+    };
+    const float pi = 3.14159265358979323846f;
+    float accu = 0.0f, a0 = 0.0f, f0 = 0.0f;
+    for (size_t i = dc_cut; i < n; ++i) {
+        const float f = frequencies[i], sp = phase_psd[i];
+        if (!(f <= clip / tau))
+            break;
+        const float sy = sp * f * f;
+        const float pft = pi * (f * tau);
+        const float hahd = powi(sinf(pft), sinx_exp) * powi(pft, x_exp);
+        const float a = sy * hahd;
+        accu = accu + (a + a0) * (f - f0);
+        a0 = a;
+        f0 = f;
+    }
+    return accu;
+}
+
+int psdc_hbf_dec8(int device, const float *x, size_t len, float *y)
+{
+    const size_t nout = len / 8;
+    if (nout == 0)
+        return PSDC_OK;
+    if (!x || !y)
+        return fail(nullptr, PSDC_ERR_ARG, "null argument");
+    psdc_handle *h = nullptr;
+    HIPCHK(h, hipSetDevice(device));
+    float *dx = nullptr, *dy = nullptr;
+    HIPCHK(h, hipMalloc(&dx, sizeof(float) * nout * 8));
+    HIPCHK(h, hipMalloc(&dy, sizeof(float) * nout));
+    HIPCHK(h, hipMemcpy(dx, x, sizeof(float) * nout * 8, hipMemcpyHostToDevice));
+    size_t done = 0;
+    while (done < nout) {
+        DecBatch db{};
+        db.drain = 0;
+        const size_t chunk = std::min<size_t>(nout - done, (size_t)1 << 24);
+        DecJob &dj = db.jobs[db.njobs++];
+        dj.src = dx;
+        dj.src_base = 0;
+        dj.m0 = (long long)done;
+        dj.dst = dy;
+        dj.dst_base = 0;
+        dj.nout = (int)chunk;
+        dj.tile_begin = 0;
+        db.ntiles = (int)((chunk + DEC_TILE - 1) / DEC_TILE);
+        HIPCHK(h, launch_dec(db, nullptr));
+        done += chunk;
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(y, dy, sizeof(float) * nout, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipFree(dx));
+    HIPCHK(h, hipFree(dy));
+    return PSDC_OK;
+}
+
+int psdc_fill_noise_device(int device, float *d_x, size_t len, uint64_t seed, uint64_t first_index)
+{
+    psdc_handle *h = nullptr;
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, launch_fill_noise(d_x, len, seed, first_index, nullptr));
+    HIPCHK(h, hipStreamSynchronize(nullptr));
+    return PSDC_OK;
+}
+
+int psdc_profile_read(psdc_handle *h, psdc_profile *out, int reset)
+{
+    if (!h || !out)
+        return fail(h, PSDC_ERR_ARG, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = collect_profile(h);
+    if (rc)
+        return rc;
+    *out = h->prof;
+    if (reset)
+        h->prof = psdc_profile{};
+    return PSDC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,355 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical f32 input.
+
+Reference behaviour under test: src/psd.rs:196-269 (segment loop), :75-113 (detrend),
+:218-233 (EWMA), :246-260 (decimate + drain), :456-468 (cascade), :479-543 (stitch).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_psd_close, test_signal as make_signal
+
+pytestmark = pytest.mark.gpu
+
+
+def check_against_oracle(pkg, ora, gpu, x_chunks, n, detrend="none", avg=None, window="hann",
+                         channel=0, what=""):
+    ref = ora.PsdCascade(n, "f64", window=window)
+    ref.set_detrend(detrend)
+    if avg is not None:
+        ref.set_avg(avg.limit, avg.count)
+    for c in x_chunks:
+        ref.process(c)
+    ns = gpu.num_stages(channel)
+    assert ns == ref.num_stages, f"{what}: stages {ns} vs {ref.num_stages}"
+    worst = 0.0
+    for k in range(ns):
+        gi, ri = gpu.stage_info(channel, k), ref.stage_info(k)
+        assert gi == ri, f"{what}: stage {k} info {gi} vs {ri}"
+        if ri["count"] == 0:
+            assert np.all(gpu.stage_spectrum(channel, k) == 0)
+        else:
+            worst = max(worst, assert_psd_close(gpu.stage_spectrum(channel, k), ref.stage_spectrum(k),
+                                                f"{what} stage {k} spectrum"))
+        assert gpu.stage_gain(channel, k) == pytest.approx(ref.stage_gain(k), rel=1e-6)
+        # pending samples of every stage: stage >= 1 streams are decimator output
+        gb, rb = gpu.stage_buf(channel, k), ref.stage_buf(k)
+        assert gb.shape == rb.shape
+        if rb.size:
+            scale = max(1e-3, float(np.max(np.abs(rb))))
+            assert np.max(np.abs(gb - rb)) <= 2e-6 * scale * (8 ** min(k, 3)) ** 0.5 + 1e-6 * scale, \
+                f"{what}: stage {k} pending samples differ by {np.max(np.abs(gb - rb))}"
+    for opts in (pkg.MergeOpts(), pkg.MergeOpts(True, 0, True), pkg.MergeOpts(False, 2, False)):
+        p, br = gpu.psd(channel, opts)
+        pr, brr, cbr = ref.psd(opts.keep_overlap, opts.min_count, opts.keep_transition_band)
+        assert len(br) == len(brr)
+        for b, r in zip(br, brr):
+            assert (b.start, b.include, b.count, b.avg, b.bins.start, b.bins.stop, b.fft_size,
+                    b.decimation, b.pending, b.processed) == (
+                r["start"], bool(r["include"]), r["count"], r["avg"], r["bins_start"], r["bins_end"],
+                r["fft_size"], r["decimation"], r["pending"], r["processed"]), f"{what}: break {b} vs {r}"
+        assert_psd_close(p, pr, f"{what} merged psd {opts}")
+        if any(b.include for b in br):
+            f = pkg.Break.frequencies(br)
+            assert np.array_equal(f, ref.frequencies(cbr))
+    return worst
+
+
+@pytest.mark.parametrize("n,total", [(16, 5000), (64, 40000), (256, 70001), (512, 65536),
+                                     (1024, 300000), (2048, 200000), (4096, 600000), (16384, 700000)])
+def test_cascade_parity_sizes(pkg, ora, gpu_required, n, total):
+    x = make_signal(pkg, total, seed=100 + n, tone=0.5, dc=0.1)
+    g = pkg.PsdCascadeBank(n)
+    g.process(0, x)
+    check_against_oracle(pkg, ora, g, [x], n, what=f"N={n}")
+    g.close()
+
+
+@pytest.mark.parametrize("detrend", ["none", "midpoint", "span", "mean"])
+@pytest.mark.parametrize("n", [64, 1024, 4096])
+def test_detrend_parity(pkg, ora, gpu_required, n, detrend):
+    x = make_signal(pkg, 40 * n + 123, seed=7 + n, tone=1.0, dc=3.0, f0=0.2 / n)
+    g = pkg.PsdCascadeBank(n)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    g.process(0, x)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, what=f"N={n} {detrend}")
+    g.close()
+
+
+def test_reference_statistical_test(pkg, gpu_required):
+    """src/psd.rs:599-644 verbatim (Psd<512> and PsdCascade<512> on unit white noise)."""
+    rng = np.random.default_rng()  # unseeded like the reference's rand::random
+    x = ((rng.random(1 << 16, dtype=np.float32) - np.float32(0.5)) * np.float32(np.sqrt(12))).astype(np.float32)
+    xm = float(np.sum(x.astype(np.float64))) / x.size
+    assert abs(xm) < 10.0 / np.sqrt(x.size)
+    xv = float(np.sum((x * x).astype(np.float64))) / x.size
+    assert abs(xv - 1.0) < 10.0 / np.sqrt(x.size)
+    n = 1 << 9
+    d = pkg.PsdCascade(n)
+    d.process(x)
+    # single stage (:615-632): output length and stage PSD
+    d_len = (x.size >> 3) - pkg.hbf_response_length(3)  # :622
+    info1 = d.stage_info(1)
+    assert info1["pending"] + info1["count"] * (n // 2) == d_len
+    p0 = d.stage_spectrum(0) / d.stage_gain(0)
+    assert np.all(np.abs(p0 * 0.5 - 1.0) < 10.0 / np.sqrt(d.stage_count(0)))
+    # cascade (:634-643)
+    p, br = d.psd(pkg.MergeOpts())
+    for b in br:
+        seg = p[b.start:b.start + len(b.bins)] if b.include else p[:0]
+        assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(max(b.count, 1)))
+    d.close()
+
+
+def test_chunking_invariance(pkg, ora, gpu_required):
+    """Results depend only on the concatenated stream (src/psd.rs:196-208)."""
+    n = 256
+    x = make_signal(pkg, 150000, seed=5, tone=0.3)
+    rng = np.random.default_rng(3)
+    one = pkg.PsdCascadeBank(n)
+    one.process(0, x)
+    many = pkg.PsdCascadeBank(n)
+    many.configure(quantum=1000)  # forces many launches with carried tails
+    chunks, i = [], 0
+    while i < x.size:
+        m = int(rng.integers(0, 3000))
+        chunks.append(x[i:i + m])
+        i += m
+    for c in chunks:
+        many.process(0, c)
+        if rng.random() < 0.05:
+            many.flush()
+    check_against_oracle(pkg, ora, many, chunks, n, what="chunked")
+    for k in range(one.num_stages()):
+        assert one.stage_info(0, k) == many.stage_info(0, k)
+        a, b = one.stage_spectrum(0, k), many.stage_spectrum(0, k)
+        assert np.allclose(a, b, rtol=2e-6, atol=1e-6 * float(np.mean(a)))
+    one.close()
+    many.close()
+
+
+@pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (0xFFFFFFFF, 40), (5, 1000), (0, 7), (1, 1)])
+def test_ewma_parity(pkg, ora, gpu_required, limit, count):
+    """Finite averaging (src/psd.rs:218-233, :431-436)."""
+    n = 64
+    x = make_signal(pkg, 60000, seed=11, tone=0.2)
+    avg = pkg.AvgOpts(limit, count)
+    g = pkg.PsdCascadeBank(n)
+    g.configure(quantum=7000)
+    g.set_avg(avg)
+    chunks = [x[:20000], x[20000:20011], x[20011:]]
+    for c in chunks:
+        g.process(0, c)
+    check_against_oracle(pkg, ora, g, chunks, n, avg=avg, what=f"ewma {limit},{count}")
+    g.close()
+
+
+def test_settings_change_midstream(pkg, ora, gpu_required):
+    n = 128
+    x = make_signal(pkg, 50000, seed=21, dc=2.0)
+    g = pkg.PsdCascadeBank(n)
+    ref = ora.PsdCascade(n, "f64")
+    g.process(0, x[:17777])
+    ref.process(x[:17777])
+    g.set_detrend(pkg.Detrend.MEAN)
+    ref.set_detrend("mean")
+    g.process(0, x[17777:30000])
+    ref.process(x[17777:30000])
+    g.set_avg(pkg.AvgOpts(20, 20))
+    ref.set_avg(20, 20)
+    g.process(0, x[30000:])
+    ref.process(x[30000:])
+    for k in range(ref.num_stages):
+        assert g.stage_info(0, k) == ref.stage_info(k)
+        if ref.stage_info(k)["count"]:
+            assert_psd_close(g.stage_spectrum(0, k), ref.stage_spectrum(k), f"stage {k}")
+    g.close()
+
+
+def test_rectangular_window(pkg, ora, gpu_required):
+    n = 128
+    x = make_signal(pkg, 30000, seed=31, tone=0.4)
+    g = pkg.PsdCascadeBank(n, window=pkg.Window.RECTANGULAR)
+    g.process(0, x)
+    check_against_oracle(pkg, ora, g, [x], n, window="rect", what="rect")
+    g.close()
+
+
+def test_decimator_alone(pkg, ora, gpu_required):
+    """HbfDec8 block (src/psd.rs:246-253) vs the oracle's f64 cascade."""
+    x = make_signal(pkg, 8 * 10000, seed=41, tone=1.0, f0=0.01)
+    y = pkg.hbf_dec8(x)
+    yr = ora.hbf_dec8(x, "f64")
+    assert y.shape == yr.shape
+    assert np.max(np.abs(y - yr)) <= 4e-6 * np.max(np.abs(yr))
+    # DC gain of the /8 cascade is 8 (src/psd.rs:516 with :634-643)
+    dc = pkg.hbf_dec8(np.ones(8 * 400, dtype=np.float32))
+    assert abs(dc[-1] - 8.0) < 8 * 2e-4
+
+
+def test_edges(pkg, ora, gpu_required):
+    n = 64
+    g = pkg.PsdCascadeBank(n, 2)
+    assert g.num_stages(0) == 0
+    p, br = g.psd(0)
+    assert p.size == 0 and br == []
+    g.process(0, np.zeros(0, dtype=np.float32))
+    assert g.num_stages(0) == 0  # empty input creates no stage (src/psd.rs:459)
+    g.process(0, np.ones(10, dtype=np.float32))
+    assert g.num_stages(0) == 1 and g.num_stages(1) == 0
+    assert g.stage_info(0, 0) == {"count": 0, "avg": 0xFFFFFFFF, "pending": 10, "processed": 0}
+    assert np.array_equal(g.stage_buf(0, 0), np.ones(10, dtype=np.float32))
+    p, br = g.psd(0)
+    assert p.size == 0 and len(br) == 1 and not br[0].include
+    with pytest.raises(pkg.PsdError) as e:
+        g.set_detrend(pkg.Detrend.LINEAR)  # unimplemented!() src/psd.rs:110
+    assert e.value.code == pkg.ERR_UNIMPLEMENTED
+    with pytest.raises(pkg.PsdError):
+        g.process(5, np.ones(4, dtype=np.float32))
+    with pytest.raises(pkg.PsdError):
+        g.stage_spectrum(0, 3)
+    with pytest.raises(pkg.PsdError):
+        pkg.PsdCascadeBank(100)  # not a supported FFT size
+    g.reset()
+    assert g.num_stages(0) == 0
+    g.close()
+
+
+def test_clone_and_reset(pkg, ora, gpu_required):
+    n = 64
+    x = make_signal(pkg, 30000, seed=51)
+    a = pkg.PsdCascadeBank(n)
+    a.process(0, x[:12345])
+    b = a.clone()  # #[derive(Clone)] src/psd.rs:399
+    a.process(0, x[12345:])
+    b.process(0, x[12345:])
+    for k in range(a.num_stages()):
+        assert a.stage_info(0, k) == b.stage_info(0, k)
+        assert np.array_equal(a.stage_spectrum(0, k), b.stage_spectrum(0, k))
+    check_against_oracle(pkg, ora, b, [x], n, what="clone")
+    a.reset()
+    a.process(0, x)
+    check_against_oracle(pkg, ora, a, [x], n, what="after reset")
+    a.close()
+    b.close()
+
+
+def test_multichannel_bank(pkg, ora, gpu_required):
+    """One cascade per trace, batched on one GPU (src/bin/psd.rs:174-182)."""
+    n, nch = 256, 5
+    xs = [make_signal(pkg, 40000 + 1000 * c, seed=0x7654321 + c, tone=0.1 * c) for c in range(nch)]
+    g = pkg.PsdCascadeBank(n, nch)
+    g.configure(quantum=8192)
+    step = 4096
+    for i in range(0, 46000, step):  # round-robin feed like the receiver loop
+        for c in range(nch):
+            g.process(c, xs[c][i:i + step])
+    for c in range(nch):
+        check_against_oracle(pkg, ora, g, [xs[c]], n, channel=c, what=f"channel {c}")
+    g.close()
+
+
+def test_device_resident_input(pkg, ora, gpu_required):
+    """psdc_process_device reads the stream in place (zero-copy spans + seam)."""
+    import torch
+    n = 1024
+    x = make_signal(pkg, 700001, seed=61, tone=0.2)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()  # the library runs on its own stream
+    g = pkg.PsdCascadeBank(n)
+    cuts = [0, 300000, 300007, 300007 + 5 * n, 620001, x.size]  # long, short, odd-aligned spans
+    chunks = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g.process_device(0, xd.data_ptr() + 4 * a, b - a)
+        chunks.append(x[a:b])
+    g.sync()
+    check_against_oracle(pkg, ora, g, chunks, n, what="device input")
+    # mixing host-fed and device-fed samples keeps the stream order
+    g2 = pkg.PsdCascadeBank(n)
+    g2.process(0, x[:1000])
+    g2.process_device(0, xd.data_ptr() + 4 * 1000, 500000)
+    g2.process(0, x[501000:])
+    check_against_oracle(pkg, ora, g2, [x], n, what="mixed input")
+    g.close()
+    g2.close()
+
+
+def test_noise_generator_twin(pkg, gpu_required):
+    import torch
+    d = torch.empty(10000, dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), d.numel(), seed=0x7654321, first_index=12345)
+    assert np.array_equal(d.cpu().numpy(), pkg.noise_host(10000, 0x7654321, 12345))
+
+
+def test_adcdac_frames(pkg, ora, gpu_required):
+    """Config 3 shape: dual-iir frames -> 4 traces -> 4 cascades (src/de/data.rs:11-82)."""
+    n, batches, nframes = 256, 22, 300
+    rng = np.random.default_rng(9)
+    raw = rng.integers(-32768, 32768, size=(4, nframes * batches * 8)).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, batches, seq0=1000)
+    assert fs == 8 + 64 * batches
+    g = pkg.PsdCascadeBank(n, 4)
+    assert g.process_adcdac_frames(data[:100 * fs], fs) == 100
+    assert g.process_adcdac_frames(data[100 * fs:], fs) == nframes - 100
+    traces = [[] for _ in range(4)]
+    for f in range(nframes):
+        st, seq, nb, tr = ora.adcdac_decode(data[f * fs:(f + 1) * fs])
+        assert st == 0 and nb == batches and seq == 1000 + f * batches
+        for c in range(4):
+            traces[c].append(tr[c])
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [np.concatenate(traces[c])], n, channel=c, what=pkg.ADCDAC_TRACES[c])
+    # de::Error cases (src/de/frame.rs:27-30, src/de/data.rs:23-24)
+    bad = bytearray(data[:3 * fs])
+    bad[fs] = 0
+    with pytest.raises(pkg.FrameError) as e:
+        g.process_adcdac_frames(bytes(bad), fs)
+    assert e.value.code == pkg.ERR_FRAME_HEADER
+    bad = bytearray(data[:fs])
+    bad[2] = 9
+    with pytest.raises(pkg.FrameError) as e:
+        g.process_adcdac_frames(bytes(bad), fs)
+    assert e.value.code == pkg.ERR_FRAME_FORMAT
+    bad = bytearray(data[:fs])
+    bad[3] = batches + 1
+    with pytest.raises(pkg.FrameError) as e:
+        g.process_adcdac_frames(bytes(bad), fs)
+    assert e.value.code == pkg.ERR_FRAME_SIZE
+    g.close()
+
+
+def test_full_size_properties(pkg, gpu_required):
+    """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
+    import torch
+    n, total = 1024, 1 << 26
+    d = torch.empty(total, dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), total, seed=0x7654321)
+    g = pkg.PsdCascadeBank(n)
+    g.process_device(0, d.data_ptr(), total)
+    plan = pkg.plan_counts(n, total)
+    assert g.num_stages() == len(plan) and len(plan) >= 6
+    for k, (recv, segs, pend) in enumerate(plan):
+        info = g.stage_info(0, k)
+        assert (info["count"], info["pending"]) == (segs, pend)
+    p, br = g.psd()
+    f = pkg.Break.frequencies(br)
+    assert f[0] == 0.0 and f[-1] == 0.5 and np.all(np.diff(f) > 0)
+    # white noise of variance 1 reads PSD = 2 in every included bin of every stage
+    for b in br:
+        if b.include:
+            seg = p[b.start:b.start + len(b.bins)]
+            assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(b.count)), b
+    # determinism: the same stream twice gives bit-identical accumulators
+    g2 = pkg.PsdCascadeBank(n)
+    g2.process_device(0, d.data_ptr(), total)
+    for k in range(len(plan)):
+        assert np.array_equal(g.stage_spectrum(0, k), g2.stage_spectrum(0, k))
+    # scaling: PSD(a x) = a^2 PSD(x) (power of two: exact in f32)
+    g2.sync()
+    d.mul_(4.0)
+    torch.cuda.synchronize()
+    g3 = pkg.PsdCascadeBank(n)
+    g3.process_device(0, d.data_ptr(), total)
+    for k in range(len(plan)):
+        assert np.array_equal(g3.stage_spectrum(0, k), 16.0 * g.stage_spectrum(0, k))
+    for h in (g, g2, g3):
+        h.close()

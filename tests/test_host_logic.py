@@ -1,0 +1,129 @@
+"""CPU-only tests of the host side: C-ABI exports, bookkeeping planner, stitch, helpers,
+and that the product path fails loudly (no CPU fallback) when there is no GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "psdcascade.h")).read()
+    declared = sorted(set(re.findall(r"\b(psdc_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = pkg.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libpsdcascade.so does not export {name}"
+    assert sorted(pkg.EXPORTS) == declared
+    assert L.psdc_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (psdc_[a-z0-9_]+)", out))
+    assert exported == set(declared)
+
+
+def test_library_does_not_link_the_oracle(pkg):
+    out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ora_" not in syms
+    for f in os.listdir(os.path.join(ROOT, "stabilizer-stream_amd", "csrc")):
+        src = open(os.path.join(ROOT, "stabilizer-stream_amd", "csrc", f), errors="ignore").read()
+        assert "oracle/" not in src.replace("oracle/hbf_taps_oracle.h, then", "") and "ora_" not in src, f
+    init = open(os.path.join(ROOT, "stabilizer-stream_amd", "__init__.py")).read()
+    assert "oracle" not in init.lower()
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(pkg):
+    with pytest.raises(pkg.PsdError) as e:
+        pkg.PsdCascade(1024)
+    assert e.value.code == pkg.ERR_DEVICE and "no CPU fallback" in str(e.value)
+    with pytest.raises(pkg.PsdError):
+        pkg.hbf_dec8(np.zeros(64, dtype=np.float32))
+
+
+def test_host_programs(pkg):
+    """fft_emul runs the device FFT code lane by lane; plan_check simulates the reference loop."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.run(["make", "-C", host], check=True, stdout=subprocess.DEVNULL)
+    for prog in ("fft_emul", "plan_check"):
+        r = subprocess.run([os.path.join(host, prog)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
+    # the N=1024 frame exchange must be bank-conflict free
+    out = subprocess.run([os.path.join(host, "fft_emul")], capture_output=True, text=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("N= 1024 rot=1")][0]
+    m = re.search(r"read cycles (\d+) \(ideal (\d+)\)\s+write cycles (\d+) \(ideal (\d+)\)", line)
+    assert m.group(1) == m.group(2) and m.group(3) == m.group(4), line
+
+
+@pytest.mark.parametrize("n,window", [(16, "hann"), (64, "hann"), (512, "hann"), (1024, "hann"),
+                                      (128, "rect"), (4096, "hann")])
+def test_plan_counts_match_the_oracle(pkg, ora, n, window):
+    rng = np.random.default_rng(n)
+    wk = pkg.Window.HANN if window == "hann" else pkg.Window.RECTANGULAR
+    for total in [0, 1, n - 1, n, n + 1, 3 * n, 17 * n + 5, 300 * n + 77, int(rng.integers(1, 700 * n))]:
+        o = ora.PsdCascade(n, "f32", window=window)
+        o.process(np.zeros(total, dtype=np.float32))
+        plan = pkg.plan_counts(n, total, wk)
+        assert len(plan) == o.num_stages, (n, total)
+        for k, (recv, segs, pend) in enumerate(plan):
+            info = o.stage_info(k)
+            assert (segs, pend) == (info["count"], info["pending"]), (n, total, k)
+    assert pkg.hbf_response_length(3) == ora.hbf_response_length(3) == 35
+
+
+@pytest.mark.parametrize("n", [64, 1024])
+def test_stitch_matches_the_oracle(pkg, ora, n):
+    """psdc_stitch (host part of PsdCascade::psd, src/psd.rs:479-543) on the oracle's f32 stage data."""
+    x = np.random.default_rng(5).standard_normal(700 * n).astype(np.float32)
+    o = ora.PsdCascade(n, "f32")
+    o.process(x)
+    ns = o.num_stages
+    infos = [o.stage_info(k) for k in range(ns)]
+    spectra = np.stack([o.stage_spectrum(k) for k in range(ns)])
+    for opts in (pkg.MergeOpts(), pkg.MergeOpts(True, 0, True), pkg.MergeOpts(False, 3, False),
+                 pkg.MergeOpts(True, 1, False), pkg.MergeOpts(False, 10 ** 6, True)):
+        p, br = pkg.stitch(n, [i["count"] for i in infos], [i["avg"] for i in infos],
+                           [i["pending"] for i in infos], spectra, opts)
+        pr, brr, cbr = o.psd(opts.keep_overlap, opts.min_count, opts.keep_transition_band)
+        assert np.array_equal(p, pr, equal_nan=True)  # same f32 ops in the same order (count 0 with min_count 0 gives NaN, like the reference)
+        assert len(br) == len(brr)
+        for b, r in zip(br, brr):
+            assert (b.start, b.include, b.count, b.avg, b.bins.start, b.bins.stop, b.fft_size,
+                    b.decimation, b.pending, b.processed) == (
+                r["start"], bool(r["include"]), r["count"], r["avg"], r["bins_start"], r["bins_end"],
+                r["fft_size"], r["decimation"], r["pending"], r["processed"])
+        assert np.array_equal(pkg.Break.frequencies(br), o.frequencies(cbr))
+        if br and br[0].include:
+            assert br[-1].rbw() == pytest.approx(1.0 / n) and br[0].effective_fft_size() == n * br[0].decimation
+
+
+def test_var_and_noise_helpers(pkg, ora):
+    p, f = [1000.0, 100.0, 1.2, 3.4, 5.6], [0.0, 1.0, 3.0, 6.0, 9.0]
+    assert abs(pkg.var_eval(p, f, 2.7) - 0.13478442) < 1e-6  # src/var.rs:52-60
+    assert pkg.var_eval(p, f, 2.7) == ora.var_eval(p, f, 2.7)
+    assert pkg.var_eval(p, f, 0.3, x_exp=-4, sinx_exp=6, clip=1.0) == ora.var_eval(p, f, 0.3, -4, 6, 1.0)
+    x = pkg.noise_host(1 << 16, 0x7654321)
+    assert x.dtype == np.float32 and abs(float(x.mean())) < 10 / 256 and abs(float((x * x).mean()) - 1) < 10 / 256
+    assert np.array_equal(pkg.noise_host(100, 5, 50), pkg.noise_host(150, 5)[50:])
+
+
+def test_adcdac_frame_builder_roundtrip(pkg, ora):
+    raw = np.random.default_rng(1).integers(-32768, 32768, size=(4, 8 * 5 * 7)).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, 5, seq0=0xFFFFFFFE)  # seq wraps (src/loss.rs wrapping_sub)
+    assert fs == 8 + 64 * 5 and len(data) == 7 * fs
+    got = [[] for _ in range(4)]
+    for i in range(7):
+        st, seq, nb, tr = ora.adcdac_decode(data[i * fs:(i + 1) * fs])
+        assert st == 0 and nb == 5 and seq == (0xFFFFFFFE + 5 * i) % 2 ** 32
+        for c in range(4):
+            got[c].append(tr[c])
+    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)
+    assert np.array_equal(np.concatenate(got[0]), raw[0].astype(np.float32) * lsb)
+    dac = ((raw[3].astype(np.int32) + 65536) % 65536 ^ 0x8000).astype(np.uint16).view(np.int16)
+    assert np.array_equal(np.concatenate(got[3]), dac.astype(np.float32) * lsb)

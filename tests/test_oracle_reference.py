@@ -1,0 +1,186 @@
+"""Pin the CPU oracle against every known answer / constant the reference holds for this path
+(tests/golden/reference_known_answers.json, each entry cites its reference line)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_exact_n4(ora, prec):
+    g = GOLD["exact_n4_hann"]
+    # window + FFT + gain directly: N=4 cannot go through process() (src/psd.rs:246-247)
+    c = ora.detrend_apply(np.array(g["x"]), "none", "hann", prec)
+    X = ora.fft_forward(c, prec)
+    w, power, nenbw, ov = ora.window(g["n"], "hann", prec)
+    gain = (g["n"] // 2 * 1) * nenbw * power  # src/psd.rs:282, count = 1
+    p = np.abs(X[: g["n"] // 2 + 1]) ** 2 / gain
+    assert np.all(np.abs(p - np.array(g["psd"])) < (g["tolerance"] if prec == "f64" else 1e-6))
+    f = np.arange(g["n"] // 2 + 1) / g["n"]
+    assert np.allclose(f, g["frequencies"], atol=g["tolerance"])
+
+
+@pytest.mark.parametrize("n", [16, 512, 1024, 4096, 16384])
+def test_window_constants(ora, n):
+    w, power, nenbw, ov = ora.window(n, "hann", "f64")
+    h = GOLD["hann_constants"]
+    assert (power, nenbw, ov) == (h["power"], h["nenbw"], int(h["overlap_over_n"] * n))
+    # power = mean(w)^2, nenbw*power = mean(w^2): exact for the periodic Hann of any N
+    assert abs(np.mean(w) ** 2 - power) < 1e-12 and abs(np.mean(w * w) - nenbw * power) < 1e-12
+    assert w[0] == 0.0 and w[0] != w[-1]  # period N, not N-1 (src/psd.rs:36-41)
+    w32, *_ = ora.window(n, "hann", "f32")
+    assert np.max(np.abs(w32 - w)) < 1e-6  # f32 argument rounding of df*i (src/psd.rs:44-47)
+    r, rp, rn, ro = ora.window(n, "rect", "f64")
+    rc = GOLD["rectangular_constants"]
+    assert np.all(r == 1.0) and (rp, rn, ro) == (rc["power"], rc["nenbw"], rc["overlap"])
+
+
+@pytest.mark.parametrize("n", [4, 8, 64, 1024, 16384])
+def test_fft_is_unnormalised_forward_dft(ora, n):
+    rng = np.random.default_rng(n)
+    c = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = np.fft.fft(c)
+    assert np.max(np.abs(ora.fft_forward(c, "f64") - ref)) < 1e-9 * np.sqrt(n)
+    c32 = c.astype(np.complex64)
+    assert np.max(np.abs(ora.fft_forward(c32, "f32") - np.fft.fft(c32.astype(np.complex128)))) < 3e-6 * n ** 0.5 * np.log2(n)
+
+
+def test_detrend_variants(ora):
+    rng = np.random.default_rng(2)
+    n = 64
+    x = rng.standard_normal(n) + 5.0
+    w, *_ = ora.window(n, "hann", "f64")
+    assert np.allclose(ora.detrend_apply(x, "none", "hann", "f64").real, x * w, atol=1e-12)
+    assert np.allclose(ora.detrend_apply(x, "midpoint", "hann", "f64").real, (x - x[n // 2]) * w, atol=1e-12)
+    assert np.allclose(ora.detrend_apply(x, "mean", "hann", "f64").real, (x - x.mean()) * w, atol=1e-12)
+    ramp = x[0] + np.arange(n) * (x[-1] - x[0]) / (n - 1)
+    assert np.allclose(ora.detrend_apply(x, "span", "hann", "f64").real, (x - ramp) * w, atol=1e-10)
+    assert np.all(ora.detrend_apply(x, "mean", "hann", "f64").imag == 0)
+
+
+def test_hbf_pins(ora):
+    """What the reference pins about the idsp decimator."""
+    d = ora.hbf_response_length(3)
+    assert d == 35
+    # rate: exactly one output per 8 inputs; DC gain 8 (x2 per half-band stage)
+    y = ora.hbf_dec8(np.ones(8 * 200), "f64")
+    assert y.size == 200 and abs(y[-1] - 8.0) < 8 * 2e-4  # < 0.001 dB ripple
+    # impulse response settles within d outputs of the last non-zero input
+    last = []
+    for phase in range(8):
+        imp = np.zeros(8 * 100)
+        imp[phase] = 1.0
+        h = ora.hbf_dec8(imp, "f64")
+        last.append(int(np.nonzero(h)[0][-1]))
+        assert abs(h.sum() - 1.0) < 1e-4  # each polyphase branch has DC gain 1 (total 8)
+    assert max(last) == d
+    # pass band 0.4 of the output rate flat, alias band clean (~ -98 dB)
+    n = 8 * 4096
+    t = np.arange(n)
+    for f_out, lo, hi in [(0.05, 7.99, 8.01), (0.2, 7.99, 8.01), (0.39, 7.99, 8.01)]:
+        y = ora.hbf_dec8(np.sin(2 * np.pi * f_out / 8 * t), "f64")[200:]
+        amp = np.sqrt(2 * np.mean(y * y))
+        assert lo < amp < hi, (f_out, amp)
+    for f_in in [0.6 / 8, 1.0 / 8 + 0.3 / 8, 0.45]:  # fold into the pass band after /8
+        y = ora.hbf_dec8(np.sin(2 * np.pi * f_in * t), "f64")[200:]
+        assert np.sqrt(2 * np.mean(y * y)) < 8 * 10 ** (-95 / 20), f_in
+
+
+def test_statistical_reference_test(ora):
+    """src/psd.rs:599-644 verbatim, on the oracle (f32 mirror)."""
+    g = GOLD["statistical_test"]
+    assert GOLD["hbf_passband"]["value"] == 0.4
+    rng = np.random.default_rng()
+    x = ((rng.random(g["samples"], dtype=np.float32) - np.float32(0.5)) * np.float32(np.sqrt(12))).astype(np.float32)
+    n, k = g["n"], g["sigma_factor"]
+    s = ora.Psd(n, "f32")
+    y = s.process(x)
+    assert y.size == (x.size >> 3) - ora.hbf_response_length(3)
+    p = s.spectrum() / np.float32(s.gain())
+    assert np.all(np.abs(p * 0.5 - 1.0) < k / np.sqrt(s.count()))
+    d = ora.PsdCascade(n, "f32")
+    d.process(x)
+    p, br, _ = d.psd()
+    for b in br:
+        seg = p[b["start"]:b["start"] + b["bins_end"] - b["bins_start"]] if b["include"] else p[:0]
+        assert np.all(np.abs(seg * 0.5 - 1.0) < k / np.sqrt(max(b["count"], 1)))
+
+
+@pytest.mark.parametrize("n", [512, 1024, 4096, 16384])
+def test_merged_bin_ranges(ora, n):
+    """src/psd.rs:490-501: stitch ranges for lowest / middle / top stages."""
+    g = GOLD["merged_bins"][str(n)]
+    c = ora.PsdCascade(n, "f32")
+    total = 80 * n  # reaches 3 stages with count >= 1
+    c.process(np.random.default_rng(1).standard_normal(total).astype(np.float32))
+    p, br, _ = c.psd()
+    inc = [b for b in br if b["include"]]
+    assert len(inc) >= 3
+    assert [inc[0]["bins_start"], inc[0]["bins_end"]] == g["lowest"]
+    assert [inc[1]["bins_start"], inc[1]["bins_end"]] == g["middle"]
+    assert [inc[-1]["bins_start"], inc[-1]["bins_end"]] == g["top"]
+    f = c.frequencies(_)
+    assert f[0] == 0.0 and f[-1] == 0.5
+
+
+def test_chunk_invariance_bit_exact(ora):
+    """Any split of the stream across process() calls gives bit-identical state (src/psd.rs:196-208)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(50000).astype(np.float32)
+    a = ora.PsdCascade(64, "f32")
+    a.process(x)
+    b = ora.PsdCascade(64, "f32")
+    i = 0
+    while i < x.size:
+        m = int(rng.integers(0, 700))
+        b.process(x[i:i + m])
+        i += m
+    assert a.num_stages == b.num_stages
+    for k in range(a.num_stages):
+        assert a.stage_info(k) == b.stage_info(k)
+        assert np.array_equal(a.stage_spectrum(k), b.stage_spectrum(k))
+        assert np.array_equal(a.stage_buf(k), b.stage_buf(k))
+
+
+def test_f32_mirror_tracks_f64_truth(ora):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(200000).astype(np.float32)
+    a, b = ora.PsdCascade(1024, "f32"), ora.PsdCascade(1024, "f64")
+    for d in ("none", "mean"):
+        a.set_detrend(d)
+        b.set_detrend(d)
+        a.process(x)
+        b.process(x)
+    for k in range(b.num_stages):
+        if b.stage_info(k)["count"]:
+            r = b.stage_spectrum(k)
+            assert np.max(np.abs(a.stage_spectrum(k) - r) / r) < 2e-5
+
+
+def test_var_known_answer(ora):
+    g = GOLD["var_basic"]
+    assert abs(ora.var_eval(g["p"], g["f"], g["tau"]) - g["value"]) < g["tolerance"]
+
+
+def test_adcdac_decode(ora):
+    g = GOLD["adcdac"]
+    b = 3
+    raw = np.arange(4 * b * 8, dtype=np.int16).reshape(b, 4, 8) * 100 - 5000
+    frame = bytes(g["magic"]) + bytes([g["format_id"], b]) + (77).to_bytes(4, "little") + raw.astype("<i2").tobytes()
+    st, seq, nb, tr = ora.adcdac_decode(frame)
+    assert (st, seq, nb) == (0, 77, b)
+    # f32 constant arithmetic of src/de/data.rs:28-35 (DAC and ADC constants are asserted equal there)
+    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)
+    assert lsb == np.float32(5.0) / np.float32(2.0) * np.float32(4.096) / np.float32(32768)
+    assert abs(float(lsb) - g["volt_per_lsb"]) < 1e-10
+    assert np.array_equal(tr[0], raw[:, 0, :].ravel().astype(np.float32) * lsb)
+    assert np.array_equal(tr[1], raw[:, 1, :].ravel().astype(np.float32) * lsb)
+    dac = (raw[:, 2, :].ravel().astype(np.int32) + 32768 + 32768) % 65536 - 32768  # wrapping_add(i16::MIN)
+    assert np.array_equal(tr[2], dac.astype(np.float32) * lsb)
+    assert ora.adcdac_decode(b"\x00\x05" + frame[2:])[0] == -1   # InvalidHeader
+    assert ora.adcdac_decode(frame[:2] + b"\x09" + frame[3:])[0] == -2  # UnknownFormat
+    assert ora.adcdac_decode(frame[:-3])[0] == -3  # PayloadSize
+    assert ora.adcdac_decode(frame[:3] + b"\x04" + frame[4:])[0] == -4  # batches mismatch panics
