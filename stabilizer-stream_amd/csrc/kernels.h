@@ -9,17 +9,19 @@
 
 namespace psdk {
 
-constexpr int MAX_JOBS = 12;
+constexpr int MAX_JOBS = 32;
 
 // One span of consecutive segments of one (channel, stage) stream.
 struct SegJob {
     const float *src;    // sample with absolute stream index i is src[i - src_base]
     long long src_base;
     long long seg0;      // absolute index of the first segment (segment j starts at j*hop)
-    float *partial;      // [ntiles][n] power partials, natural bin order
+    float *partial;      // [nblocks][n] power partials, natural bin order
     double log2_gamma;   // EWMA: log2(avg/(avg+1)); -inf when avg == 0
     int nseg;            // segments in this span
-    int tile_begin;      // first tile of this job within the launch
+    int block_begin;     // first workgroup of this job within the launch
+    int nblocks;         // workgroups of this job; workgroup b walks tiles b, b+nblocks, ...
+    int ntiles;          // tiles (of welch_segments_per_tile segments) in this span
     int step0;           // EWMA: 1-based batch step of seg0
     int nb;              // EWMA: steps in the whole (channel, stage) batch
     int is_m1;           // EWMA: i_s - 1
@@ -28,7 +30,7 @@ struct SegJob {
 
 struct WelchBatch {
     int njobs;
-    int ntiles;
+    int nblocks; // grid size
     int hop;
     int detrend;
     SegJob jobs[MAX_JOBS];
@@ -53,12 +55,12 @@ struct DecBatch {
 };
 
 // Fold the partials of one (channel, stage) into its spectrum accumulator:
-// spectrum[k] = g_total*spectrum[k] + 0.5*sum_t (P[t][k] + P[t][(n-k)%n]).
+// spectrum[k] = g_total*spectrum[k] + 0.5*sum_b (P[b][k] + P[b][(n-k)%n]).
 struct RedJob {
     const float *partial;
     float *spectrum;
     float g_total;
-    int ntiles;
+    int nparts;
 };
 
 struct RedBatch {
@@ -81,6 +83,7 @@ struct TailBatch {
 
 // tile geometry (host needs it to size partial slabs and grids)
 int welch_segments_per_tile(int n);
+constexpr int WELCH_MAX_BLOCKS = 1024; // persistent workgroups per launch (4 per CU)
 constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 
 bool welch_supported(int n);

@@ -75,16 +75,12 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
     __shared__ cf frames[TEAMS * N];
     __shared__ float red[Cfg::WAVES * 2];
 
-    // tile -> job
-    const int tile = blockIdx.x;
+    // workgroup -> job; this workgroup walks the job's tiles lt = wb, wb + nblocks, ...
     int ji = 0;
-    while (ji + 1 < batch.njobs && tile >= batch.jobs[ji + 1].tile_begin)
+    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
         ++ji;
     const SegJob &job = batch.jobs[ji];
-    const int lt = tile - job.tile_begin;
-    const int seg_lo = lt * SPT;
-    const int seg_hi = min(job.nseg, seg_lo + SPT);
-    const int npairs = (seg_hi - seg_lo + 1) >> 1;
+    const int wb = blockIdx.x - job.block_begin;
 
     const int team = threadIdx.x / TEAM;
     const int t = threadIdx.x % TEAM;
@@ -97,6 +93,10 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
     for (int s = 0; s < E; ++s)
         q[s] = 0.0f;
 
+    for (int lt = wb; lt < job.ntiles; lt += job.nblocks) {
+    const int seg_lo = lt * SPT;
+    const int seg_hi = min(job.nseg, seg_lo + SPT);
+    const int npairs = (seg_hi - seg_lo + 1) >> 1;
     for (int p0 = 0; p0 < npairs; p0 += TEAMS) {
         const int p = p0 + team;
         const int la = seg_lo + 2 * p; // local segment index of the "real" lane
@@ -196,15 +196,16 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
         for (int s = 0; s < E; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
     }
+    }
 
-    // combine the teams and write the tile's partial in natural bin order
+    // combine the teams and write the workgroup's partial in natural bin order
     float *fq = reinterpret_cast<float *>(frames);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < E; ++s)
         fq[team * N + freq_of_slot<N>(t, s)] = q[s];
     __syncthreads();
-    float *out = job.partial + (size_t)lt * N;
+    float *out = job.partial + (size_t)wb * N;
     for (int k = threadIdx.x; k < N; k += Cfg::BLOCK) {
         float acc = 0.0f;
 #pragma unroll
@@ -314,20 +315,33 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
 // reduce / tail / fill / adcdac
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void reduce_kernel(const RedBatch batch)
+constexpr int RED_BINS = 32, RED_SLICES = 32; // 1024 threads: 32 bins x 32 slices of the partial list
+
+__global__ __launch_bounds__(RED_BINS *RED_SLICES) void reduce_kernel(const RedBatch batch)
 {
+    __shared__ double part[RED_SLICES][RED_BINS + 1];
     const RedJob &job = batch.jobs[blockIdx.y];
     const int n = batch.n;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k > n / 2)
-        return;
-    const int km = (n - k) & (n - 1);
-    double acc = 0.0;
-    for (int t = 0; t < job.ntiles; ++t) {
-        const float *p = job.partial + (size_t)t * n;
-        acc += (double)p[k] + (double)p[km];
+    const int lane = threadIdx.x % RED_BINS, slice = threadIdx.x / RED_BINS;
+    const int k = blockIdx.x * RED_BINS + lane;
+    const bool live = k <= n / 2;
+    double acc = 0.0; // f64 partial sums: the fold adds no rounding of its own
+    if (live) {
+        const int km = (n - k) & (n - 1);
+        for (int t = slice; t < job.nparts; t += RED_SLICES) {
+            const float *p = job.partial + (size_t)t * n;
+            acc += (double)p[k] + (double)p[km];
+        }
     }
-    job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && live) {
+        acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < RED_SLICES; ++i)
+            acc += part[i][lane];
+        job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+    }
 }
 
 __global__ __launch_bounds__(256) void tail_kernel(const TailBatch batch)
@@ -411,13 +425,13 @@ bool welch_supported(int n) { return welch_segments_per_tile(n) != 0; }
 
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s)
 {
-    if (b.ntiles <= 0)
+    if (b.nblocks <= 0)
         return hipSuccess;
     switch (n) {
-#define PSDK_CASE(NN)                                                                           \
-    case NN:                                                                                    \
-        hipLaunchKernelGGL(welch_kernel<NN>, dim3(b.ntiles), dim3(WelchCfg<NN>::BLOCK), 0, s, b, \
-                           win, tw);                                                            \
+#define PSDK_CASE(NN)                                                                            \
+    case NN:                                                                                     \
+        hipLaunchKernelGGL(welch_kernel<NN>, dim3(b.nblocks), dim3(WelchCfg<NN>::BLOCK), 0, s, b, \
+                           win, tw);                                                             \
         break;
         PSDK_CASE(16)
         PSDK_CASE(32)
@@ -449,7 +463,8 @@ hipError_t launch_reduce(const RedBatch &b, hipStream_t s)
 {
     if (b.njobs <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(reduce_kernel, dim3((b.n / 2 + 1 + 255) / 256, b.njobs), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(reduce_kernel, dim3((b.n / 2 + 1 + RED_BINS - 1) / RED_BINS, b.njobs),
+                       dim3(RED_BINS * RED_SLICES), 0, s, b);
     return hipGetLastError();
 }
 

@@ -204,6 +204,14 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
     return PSDC_OK;
 }
 
+// both ping-pong buffers can hold `need` floats (content of the current one is kept)
+int ensure_cap(psdc_handle *h, StageState &s, size_t need)
+{
+    if (need <= s.buf.cap)
+        return PSDC_OK;
+    return ensure_room(h, s, s.buf.base + need);
+}
+
 int ensure_partial(psdc_handle *h, size_t floats)
 {
     if (floats <= h->partial_cap)
@@ -248,12 +256,18 @@ int collect_profile(psdc_handle *h)
     return PSDC_OK;
 }
 
-// Issue every complete segment of every stage of every channel.
-int advance(psdc_handle *h)
+// One round of the cascade pipeline: every (channel, stage) that has complete
+// segments in its stream buffer is issued, all stages in the SAME launches.
+// The decimator output of this round becomes visible to the next stage in the
+// next round (stage k+1 lags one round behind stage k), so a round costs one
+// welch, one reduce, one decimator and one tail launch whatever the depth.
+// *did_work tells whether anything was issued; read-outs call rounds until idle.
+int advance_round(psdc_handle *h, bool *did_work)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
     const uint64_t seam = (uint64_t)h->n + HBF_HALO;
+    *did_work = false;
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
     // the carried tail) behind the tail; the bulk is read in place
@@ -270,13 +284,12 @@ int advance(psdc_handle *h)
         s0.buf.end = c.span.first + cp;
     }
 
-    std::vector<Work> touched;
-    for (uint32_t k = 0;; ++k) {
-        std::vector<Work> works;
-        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
-            Channel &c = h->ch[ci];
-            if (c.st.size() <= k)
-                continue;
+    // collect the work of this round from the totals as they stand now
+    std::vector<Work> works;
+    size_t tiles_total = 0;
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        Channel &c = h->ch[ci];
+        for (uint32_t k = 0; k < c.st.size(); ++k) {
             StageState &s = c.st[k];
             const uint64_t j_new = segments_for(g, s.total);
             if (j_new == s.segs)
@@ -303,201 +316,249 @@ int advance(psdc_handle *h)
             } else {
                 w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new};
             }
+            for (int i = 0; i < w.nspans; ++i)
+                tiles_total += (size_t)((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
             works.push_back(w);
         }
-        if (works.empty())
-            break;
+    }
+    if (works.empty()) {
+        for (auto &c : h->ch) {
+            if (c.has_span)
+                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
+            c.submitted = false;
+        }
+        return PSDC_OK;
+    }
+    *did_work = true;
 
-        // next-stage streams and partial slab
-        size_t tiles_total = 0;
-        for (auto &w : works) {
-            Channel &c = h->ch[w.c];
-            const uint64_t t_next = emitted_for(g, w.p_new);
-            if (t_next > 0) {
-                if (c.st.size() <= (size_t)w.k + 1) {
-                    int rc = add_stage(h, c);
-                    if (rc)
-                        return rc;
-                }
-                int rc = ensure_room(h, c.st[w.k + 1], t_next);
+    // where every stream will start after this round (its tail is carried to the
+    // front of its other buffer; the decimator appends the new samples behind it)
+    auto kf_after = [&](uint32_t ci, uint32_t k) -> uint64_t {
+        StageState t = h->ch[ci].st[k];
+        for (auto &w : works)
+            if (w.c == ci && w.k == k) {
+                t.segs = w.j_new;
+                t.dec = w.p_new;
+            }
+        return keep_from(g, t);
+    };
+    for (auto &w : works) {
+        Channel &c = h->ch[w.c];
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        if (t_next > 0) {
+            if (c.st.size() <= (size_t)w.k + 1) {
+                int rc = add_stage(h, c);
                 if (rc)
                     return rc;
             }
-            for (int i = 0; i < w.nspans; ++i)
-                tiles_total += (size_t)((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
+            StageState &nx = c.st[w.k + 1];
+            int rc = ensure_cap(h, nx, (size_t)(t_next - kf_after(w.c, w.k + 1)));
+            if (rc)
+                return rc;
         }
-        int rc = ensure_partial(h, tiles_total * h->n);
-        if (rc)
-            return rc;
+    }
+    // stream buffers may have been reallocated by ensure_room: refresh span pointers
+    for (auto &w : works) {
+        StageState &s = h->ch[w.c].st[w.k];
+        for (int i = 0; i < w.nspans; ++i)
+            if (!(w.k == 0 && h->ch[w.c].has_span && w.spans[i].src == h->ch[w.c].span.d_x)) {
+                w.spans[i].src = s.buf.p[s.buf.cur];
+                w.spans[i].src_base = s.buf.base;
+            }
+    }
 
-        // welch + reduce, at most MAX_JOBS spans per launch
-        size_t slab = 0; // floats used in d_partial
-        size_t wi = 0;
-        while (wi < works.size()) {
-            WelchBatch wb{};
-            RedBatch rb{};
-            wb.hop = (int)g.hop;
-            wb.detrend = h->detrend;
-            rb.n = (int)h->n;
-            uint64_t samples = 0, samples0 = 0;
-            while (wi < works.size() && wb.njobs + works[wi].nspans <= MAX_JOBS) {
-                const Work &w = works[wi];
-                StageState &s = h->ch[w.c].st[w.k];
-                RedJob rj{};
-                rj.partial = h->d_partial + slab;
-                rj.spectrum = s.spectrum;
-                rj.g_total = (float)w.ew.g_total;
-                for (int i = 0; i < w.nspans; ++i) {
-                    const Span &sp = w.spans[i];
-                    const uint64_t nseg = sp.seg_b - sp.seg_a;
-                    if (nseg == 0)
-                        continue;
-                    SegJob &sj = wb.jobs[wb.njobs++];
-                    sj.src = sp.src;
-                    sj.src_base = (long long)sp.src_base;
-                    sj.seg0 = (long long)sp.seg_a;
-                    sj.partial = h->d_partial + slab;
-                    sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
-                                                      : -std::numeric_limits<double>::infinity();
-                    sj.nseg = (int)nseg;
-                    sj.tile_begin = wb.ntiles;
-                    sj.step0 = (int)(sp.seg_a - w.j_old) + 1;
-                    sj.nb = (int)w.ew.nb;
-                    sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
-                    sj.ewma = w.ew.ewma ? 1 : 0;
-                    const int nt = (int)((nseg + spt - 1) / spt);
-                    wb.ntiles += nt;
-                    rj.ntiles += nt;
-                    slab += (size_t)nt * h->n;
-                }
-                rb.jobs[rb.njobs++] = rj;
-                const uint64_t ns = w.p_new - w.p_old;
-                samples += ns;
-                if (w.k == 0)
-                    samples0 += ns;
-                ++wi;
+    // share the persistent workgroups among the spans so that every workgroup
+    // walks about the same number of tiles
+    const size_t per_block = (tiles_total + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS;
+    auto blocks_for = [&](uint64_t ntiles) -> int { return (int)((ntiles + per_block - 1) / per_block); };
+    size_t blocks_total = 0;
+    for (auto &w : works)
+        for (int i = 0; i < w.nspans; ++i)
+            blocks_total += (size_t)blocks_for((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
+    int rc = ensure_partial(h, blocks_total * h->n);
+    if (rc)
+        return rc;
+
+    // welch + reduce, at most MAX_JOBS spans per launch
+    size_t slab = 0; // floats used in d_partial
+    size_t wi = 0;
+    while (wi < works.size()) {
+        WelchBatch wb{};
+        RedBatch rb{};
+        wb.hop = (int)g.hop;
+        wb.detrend = h->detrend;
+        rb.n = (int)h->n;
+        uint64_t samples = 0, samples0 = 0;
+        while (wi < works.size() && wb.njobs + works[wi].nspans <= MAX_JOBS) {
+            const Work &w = works[wi];
+            StageState &s = h->ch[w.c].st[w.k];
+            RedJob rj{};
+            rj.partial = h->d_partial + slab;
+            rj.spectrum = s.spectrum;
+            rj.g_total = (float)w.ew.g_total;
+            for (int i = 0; i < w.nspans; ++i) {
+                const Span &sp = w.spans[i];
+                const uint64_t nseg = sp.seg_b - sp.seg_a;
+                if (nseg == 0)
+                    continue;
+                SegJob &sj = wb.jobs[wb.njobs++];
+                sj.src = sp.src;
+                sj.src_base = (long long)sp.src_base;
+                sj.seg0 = (long long)sp.seg_a;
+                sj.partial = h->d_partial + slab;
+                sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                                  : -std::numeric_limits<double>::infinity();
+                sj.nseg = (int)nseg;
+                sj.ntiles = (int)((nseg + spt - 1) / spt);
+                sj.nblocks = blocks_for((uint64_t)sj.ntiles);
+                sj.block_begin = wb.nblocks;
+                sj.step0 = (int)(sp.seg_a - w.j_old) + 1;
+                sj.nb = (int)w.ew.nb;
+                sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+                sj.ewma = w.ew.ewma ? 1 : 0;
+                wb.nblocks += sj.nblocks;
+                rj.nparts += sj.nblocks;
+                slab += (size_t)sj.nblocks * h->n;
             }
-            ProfEvents pe{};
-            if (h->profile) {
-                HIPCHK(h, hipEventCreate(&pe.a));
-                HIPCHK(h, hipEventCreate(&pe.b));
-                HIPCHK(h, hipEventRecord(pe.a, h->stream));
-            }
-            HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
-            if (h->profile) {
-                HIPCHK(h, hipEventRecord(pe.b, h->stream));
-                h->prof_pending.push_back(pe);
-                h->prof.launches += 1;
-                h->prof.samples += samples;
-                h->prof.stage0_samples += samples0;
-            }
-            HIPCHK(h, launch_reduce(rb, h->stream));
+            rb.jobs[rb.njobs++] = rj;
+            const uint64_t ns = w.p_new - w.p_old;
+            samples += ns;
+            if (w.k == 0)
+                samples0 += ns;
+            ++wi;
         }
-
-        // decimator
-        wi = 0;
-        size_t span_i = 0;
-        while (wi < works.size()) {
-            DecBatch db{};
-            db.drain = (int)g.drain;
-            while (wi < works.size() && db.njobs < MAX_JOBS) {
-                const Work &w = works[wi];
-                Channel &c = h->ch[w.c];
-                bool advanced = true;
-                for (; span_i < (size_t)w.nspans; ++span_i) {
-                    if (db.njobs >= MAX_JOBS) {
-                        advanced = false;
-                        break;
-                    }
-                    const Span &sp = w.spans[span_i];
-                    const uint64_t nout = sp.m_b - sp.m_a;
-                    if (nout == 0 || sp.m_b <= g.drain)
-                        continue; // nothing reaches the next stage yet
-                    StageState &nx = c.st[w.k + 1];
-                    DecJob &dj = db.jobs[db.njobs++];
-                    dj.src = sp.src;
-                    dj.src_base = (long long)sp.src_base;
-                    dj.m0 = (long long)sp.m_a;
-                    dj.dst = nx.buf.p[nx.buf.cur];
-                    dj.dst_base = (long long)nx.buf.base;
-                    dj.nout = (int)nout;
-                    dj.tile_begin = db.ntiles;
-                    db.ntiles += (int)((nout + DEC_TILE - 1) / DEC_TILE);
-                }
-                if (!advanced)
-                    break;
-                span_i = 0;
-                ++wi;
-            }
-            HIPCHK(h, launch_dec(db, h->stream));
+        if (slab > h->partial_cap)
+            return fail(h, PSDC_ERR_DEVICE, "internal: partial slab overflow");
+        ProfEvents pe{};
+        if (h->profile) {
+            HIPCHK(h, hipEventCreate(&pe.a));
+            HIPCHK(h, hipEventCreate(&pe.b));
+            HIPCHK(h, hipEventRecord(pe.a, h->stream));
         }
+        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
+        if (h->profile) {
+            HIPCHK(h, hipEventRecord(pe.b, h->stream));
+            h->prof_pending.push_back(pe);
+            h->prof.launches += 1;
+            h->prof.samples += samples;
+            h->prof.stage0_samples += samples0;
+        }
+        HIPCHK(h, launch_reduce(rb, h->stream));
+    }
 
-        // bookkeeping
+    // decimator: this round's outputs are appended to the next-stage streams
+    {
+        DecBatch db{};
+        db.drain = (int)g.drain;
         for (auto &w : works) {
             Channel &c = h->ch[w.c];
-            StageState &s = c.st[w.k];
-            s.count = count_after(s.count, cur_stage_avg(h, w.k), w.j_new - w.j_old);
-            s.segs = w.j_new;
-            s.dec = w.p_new;
-            const uint64_t t_next = emitted_for(g, w.p_new);
-            if (t_next > 0) {
-                c.st[w.k + 1].total = t_next;
-                c.st[w.k + 1].buf.end = t_next;
+            for (int i = 0; i < w.nspans; ++i) {
+                const Span &sp = w.spans[i];
+                const uint64_t nout = sp.m_b - sp.m_a;
+                if (nout == 0 || sp.m_b <= g.drain)
+                    continue; // nothing reaches the next stage yet
+                if (db.njobs == MAX_JOBS) {
+                    HIPCHK(h, launch_dec(db, h->stream));
+                    db = DecBatch{};
+                    db.drain = (int)g.drain;
+                }
+                StageState &nx = c.st[w.k + 1];
+                DecJob &dj = db.jobs[db.njobs++];
+                dj.src = sp.src;
+                dj.src_base = (long long)sp.src_base;
+                dj.m0 = (long long)sp.m_a;
+                dj.dst = nx.buf.p[nx.buf.cur ^ 1];
+                dj.dst_base = (long long)kf_after(w.c, w.k + 1);
+                dj.nout = (int)nout;
+                dj.tile_begin = db.ntiles;
+                db.ntiles += (int)((nout + DEC_TILE - 1) / DEC_TILE);
             }
-            touched.push_back(w);
         }
+        HIPCHK(h, launch_dec(db, h->stream));
     }
 
-    // carry the tails into the other buffer of each touched stream
+    // bookkeeping: counts and stream positions
+    std::vector<std::vector<uint64_t>> old_total(h->n_channels);
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci)
+        for (auto &s : h->ch[ci].st)
+            old_total[ci].push_back(s.total);
+    for (auto &w : works) {
+        StageState &s = h->ch[w.c].st[w.k];
+        s.count = count_after(s.count, cur_stage_avg(h, w.k), w.j_new - w.j_old);
+        s.segs = w.j_new;
+        s.dec = w.p_new;
+    }
+    for (auto &w : works) {
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        if (t_next > 0)
+            h->ch[w.c].st[w.k + 1].total = t_next; // visible to the next stage from the next round on
+    }
+
+    // carry the small tail [keep_from, old total) of every stream that consumed or
+    // received samples to the front of its other buffer, then swap
     {
         TailBatch tb{};
-        auto flush_tb = [&]() -> int {
-            if (tb.njobs) {
-                HIPCHK(h, launch_tail(tb, h->stream));
-                tb = TailBatch{};
-            }
-            return PSDC_OK;
-        };
-        for (auto &w : touched) {
-            Channel &c = h->ch[w.c];
-            StageState &s = c.st[w.k];
-            const uint64_t kf = keep_from(g, s);
-            if (kf == s.buf.base && s.buf.end == s.total)
-                continue;
-            const uint64_t cnt = s.total - kf;
-            const float *src;
-            if (w.k == 0 && c.has_span && kf >= c.span.first)
-                src = c.span.d_x + (kf - c.span.first);
-            else
-                src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
-            if (cnt > s.buf.cap)
-                return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
-            const int other = s.buf.cur ^ 1;
-            if (cnt) {
-                if (tb.njobs == MAX_JOBS) {
-                    int rc = flush_tb();
-                    if (rc)
-                        return rc;
+        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+            Channel &c = h->ch[ci];
+            for (uint32_t k = 0; k < c.st.size(); ++k) {
+                StageState &s = c.st[k];
+                const uint64_t kf = keep_from(g, s);
+                const uint64_t told = old_total[ci][k];
+                const bool received = s.total != told;
+                if (kf == s.buf.base && !received && s.buf.end == s.total)
+                    continue;
+                const bool span0 = (k == 0 && c.has_span);
+                const uint64_t cnt = told > kf ? told - kf : 0;
+                const float *src = nullptr;
+                if (span0 && kf >= c.span.first)
+                    src = c.span.d_x + (kf - c.span.first);
+                else if (span0)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
+                else if (cnt)
+                    src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
+                if (s.total - kf > s.buf.cap)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
+                const int other = s.buf.cur ^ 1;
+                if (cnt) {
+                    if (tb.njobs == MAX_JOBS) {
+                        HIPCHK(h, launch_tail(tb, h->stream));
+                        tb = TailBatch{};
+                    }
+                    tb.jobs[tb.njobs++] = {src, s.buf.p[other], (int)cnt};
                 }
-                tb.jobs[tb.njobs++] = {src, s.buf.p[other], (int)cnt};
+                s.buf.cur = other;
+                s.buf.base = kf;
+                s.buf.end = s.total;
             }
-            s.buf.cur = other;
-            s.buf.base = kf;
-            s.buf.end = s.total;
         }
-        int rc = flush_tb();
-        if (rc)
-            return rc;
+        HIPCHK(h, launch_tail(tb, h->stream));
     }
     for (auto &c : h->ch) {
-        // a span is at least 4*(n + halo) long, so it always completes segments
-        // and its tail was carried out of d_x above
-        if (c.has_span && c.st[0].buf.end != c.st[0].total)
-            return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
         c.has_span = false;
         c.submitted = false;
     }
     return PSDC_OK;
+}
+
+// one pipeline round (ingest path)
+int advance(psdc_handle *h)
+{
+    bool did = false;
+    return advance_round(h, &did);
+}
+
+// rounds until the pipeline is idle (read-out path)
+int drain(psdc_handle *h)
+{
+    for (int guard = 0; guard < 64; ++guard) {
+        bool did = false;
+        int rc = advance_round(h, &did);
+        if (rc)
+            return rc;
+        if (!did)
+            return PSDC_OK;
+    }
+    return fail(h, PSDC_ERR_DEVICE, "internal: pipeline did not drain");
 }
 
 int submit_host(psdc_handle *h, Channel &c)
@@ -565,7 +626,7 @@ int flush_all(psdc_handle *h)
         if (rc)
             return rc;
     }
-    return advance(h);
+    return drain(h);
 }
 
 int flush_sync(psdc_handle *h)
