@@ -110,22 +110,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    # read-out: every rank's raw per-stage spectra to rank 0 (one RCCL gather), then host stitch
+    # read-out: every rank's raw per-stage accumulators + counters to rank 0 in ONE RCCL gather,
+    # then the host stitch (PsdCascade::psd) per channel on rank 0
+    from stabilizer_stream_amd import shard
     ns = bank.num_stages(0)
-    kmax = 12
-    spec = torch.zeros(C, kmax, n // 2 + 1, dtype=torch.float32)
-    meta = torch.zeros(C, kmax, 2, dtype=torch.int64)
-    for c in range(C):
-        for k in range(bank.num_stages(c)):
-            spec[c, k] = torch.from_numpy(bank.stage_spectrum(c, k))
-            info = bank.stage_info(c, k)
-            meta[c, k, 0], meta[c, k, 1] = info["count"], info["pending"]
+    spec, meta = shard.pack_readout(bank, C, n, torch)
     if dist is not None:
-        spec_d, meta_d = spec.cuda(), meta.cuda()
-        gs = [torch.empty_like(spec_d) for _ in range(world)] if rank == 0 else None
-        gm = [torch.empty_like(meta_d) for _ in range(world)] if rank == 0 else None
-        dist.gather(spec_d, gs, dst=0)
-        dist.gather(meta_d, gm, dst=0)
+        specs, metas = shard.gather_readout(dist, spec, meta, device=torch.device("cuda", local_rank))
+    else:
+        specs, metas = [spec], [meta]
+    merged = shard.stitch_gathered(pkg, n, specs, metas, [C] * world) if rank == 0 else None
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -137,7 +131,8 @@ def main():
     if rank == 0:
         total_samples = float(args.steps) * T * C * world
         msps = total_samples / dt / 1e6
-        psd, breaks = bank.psd(0)
+        psd, breaks = merged[0]
+        assert len(merged) == C * world
         reached = sum(1 for b in breaks if b.include)
         kern_s = prof["kernel_ms"] * 1e-3
         ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0

@@ -1,0 +1,76 @@
+"""Channel sharding across the GPUs of one node and the read-out gather.
+
+Each trace is an independent cascade (src/bin/psd.rs:174-182), so channels shard with no
+data-path collective.  The only exchange is at read-out: every rank's raw per-stage
+accumulators and counters go to rank 0 in ONE gather (RCCL over xGMI on GPUs, gloo on CPU),
+and rank 0 runs the host stitch of PsdCascade::psd (src/psd.rs:479-543) per channel.
+Gathering the un-normalised accumulators keeps the result bit-identical to a single-GPU run.
+"""
+import numpy as np
+
+KMAX = 12  # stage slots per channel in the gather payload (8^12 * N samples: unreachable)
+
+
+def channel_shard(n_channels, world, rank):
+    """Contiguous block of global channel ids owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_channels, world)
+    lo = rank * base + min(rank, rem)
+    return list(range(lo, lo + base + (1 if rank < rem else 0)))
+
+
+def pack_readout(bank, n_local, n, torch):
+    """Raw spectra [n_local, KMAX, n/2+1] f32 and (count, avg, pending, valid) [n_local, KMAX, 4] i64."""
+    bins = n // 2 + 1
+    spec = torch.zeros(n_local, KMAX, bins, dtype=torch.float32)
+    meta = torch.zeros(n_local, KMAX, 4, dtype=torch.int64)
+    for c in range(n_local):
+        ns = bank.num_stages(c)
+        assert ns <= KMAX
+        for k in range(ns):
+            info = bank.stage_info(c, k)
+            spec[c, k] = torch.from_numpy(np.ascontiguousarray(bank.stage_spectrum(c, k), dtype=np.float32))
+            meta[c, k, 0], meta[c, k, 1], meta[c, k, 2], meta[c, k, 3] = info["count"], info["avg"], info["pending"], 1
+    return spec, meta
+
+
+def gather_readout(dist, spec, meta, device=None, dst=0):
+    """One gather of (spec, meta) to rank `dst`.  All ranks must hold equally shaped tensors
+    (pad channel blocks to the largest shard).  Returns lists on dst, (None, None) elsewhere."""
+    if device is not None:
+        spec, meta = spec.to(device), meta.to(device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import torch
+    # a single payload: meta is carried as two exact f32 halves (values < 2^48 split into 24-bit words)
+    lo = (meta & 0xFFFFFF).to(torch.float32)
+    hi = (meta >> 24).to(torch.float32)
+    payload = torch.cat([spec.reshape(spec.shape[0], -1), lo.reshape(lo.shape[0], -1),
+                         hi.reshape(hi.shape[0], -1)], dim=1).contiguous()
+    out = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, out, dst=dst)
+    if rank != dst:
+        return None, None
+    nb = spec.shape[1] * spec.shape[2]
+    nm = meta.shape[1] * meta.shape[2]
+    specs, metas = [], []
+    for p in out:
+        p = p.cpu()
+        specs.append(p[:, :nb].reshape(spec.shape))
+        lo_ = p[:, nb:nb + nm].to(torch.int64)
+        hi_ = p[:, nb + nm:nb + 2 * nm].to(torch.int64)
+        metas.append(((hi_ << 24) | lo_).reshape(meta.shape))
+    return specs, metas
+
+
+def stitch_gathered(pkg, n, specs, metas, counts_per_rank, opts=None, window=None):
+    """Merged PSD + breaks for every global channel, in rank-major channel order."""
+    opts = opts if opts is not None else pkg.MergeOpts()
+    window = window if window is not None else pkg.Window.HANN
+    results = []
+    for r, (spec, meta) in enumerate(zip(specs, metas)):
+        for c in range(counts_per_rank[r]):
+            ns = int(meta[c, :, 3].sum())
+            counts = [int(v) for v in meta[c, :ns, 0]]
+            avgs = [int(v) for v in meta[c, :ns, 1]]
+            pend = [int(v) for v in meta[c, :ns, 2]]
+            results.append(pkg.stitch(n, counts, avgs, pend, spec[c, :ns].numpy(), opts, window))
+    return results

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/psd_golden.npz from the f64 CPU oracle.
+
+These are SELF-GENERATED regression vectors (the reference ships no recorded input/output
+files); they are not reference outputs.  Inputs are not stored: they are
+`noise_host(length, seed)` (splitmix64 -> unit-variance uniform noise, src/psd.rs:604-606)
+plus a tone and an offset, regenerated bit-exactly by the tests.  Re-run after changing the
+half-band tap table (oracle/hbf_taps_oracle.h + stabilizer-stream_amd/csrc/hbf_taps.h).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+CASES = [  # name, n, length, seed, tone, dc, detrend, avg(limit,count)
+    ("n64_none", 64, 20000, 101, 0.5, 0.1, "none", None),
+    ("n64_mean_ewma", 64, 20000, 102, 0.5, 2.0, "mean", (6, 100)),
+    ("n1024_none", 1024, 200000, 103, 0.25, 0.0, "none", None),
+    ("n1024_span", 1024, 200000, 104, 0.25, 1.0, "span", None),
+    ("n4096_midpoint", 4096, 300000, 105, 0.0, 0.5, "midpoint", None),
+]
+
+
+def signal(pkg, length, seed, tone, dc):
+    x = pkg.noise_host(length, seed)
+    if tone:
+        x = x + np.float32(tone) * np.sin(2 * np.pi * 0.01234 * np.arange(length)).astype(np.float32)
+    if dc:
+        x = x + np.float32(dc)
+    return x.astype(np.float32)
+
+
+def main():
+    pkg, ora = entry.load_package(), entry.load_oracle()
+    out = {}
+    for name, n, length, seed, tone, dc, detrend, avg in CASES:
+        c = ora.PsdCascade(n, "f64")
+        c.set_detrend(detrend)
+        if avg:
+            c.set_avg(*avg)
+        c.process(signal(pkg, length, seed, tone, dc))
+        ns = c.num_stages
+        out[f"{name}/counts"] = np.array([c.stage_info(k)["count"] for k in range(ns)], dtype=np.int64)
+        out[f"{name}/pending"] = np.array([c.stage_info(k)["pending"] for k in range(ns)], dtype=np.int64)
+        out[f"{name}/spectra"] = np.stack([c.stage_spectrum(k) for k in range(ns)])
+        p, br, _ = c.psd()
+        out[f"{name}/psd"] = p
+    np.savez_compressed(os.path.join(os.path.dirname(__file__), "psd_golden.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
