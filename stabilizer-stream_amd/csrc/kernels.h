@@ -69,6 +69,30 @@ struct RedBatch {
     RedJob jobs[MAX_JOBS];
 };
 
+// Fused fast path (N = 1024, Hann, Detrend::None, plain sum): a run of whole
+// segment PAIRS.  Pair i = segments (seg_a + 2i, seg_a + 2i + 1) = samples
+// src[1024 i .. 1024 i + 1536); its 1024 new samples src[1024 i + 512 ..) are
+// decimated to 128 outputs dst[128 i ..).  src must be 16-byte aligned.
+struct FusedJob {
+    const float *src;   // first sample of segment seg_a
+    float *dst;         // where decimator output 64 (seg_a + 1) lands in the next stage's stream
+    float *partial;     // [nblocks][1024]
+    int npairs;
+    int run;            // pairs per wavefront run (tile = 8 waves x run pairs)
+    int block_begin;
+    int nblocks;
+};
+
+struct FusedBatch {
+    int njobs;
+    int nblocks;
+    FusedJob jobs[MAX_JOBS];
+};
+
+constexpr int FUSED_WAVES = 8;        // wavefronts per workgroup
+constexpr int FUSED_MAX_RUN = 8;      // pairs per wavefront run
+constexpr int FUSED_MAX_BLOCKS = 512; // 2 workgroups per CU
+
 // Carry the unconsumed tail of a stream to the front of its other buffer.
 struct TailJob {
     const float *src;
@@ -88,6 +112,7 @@ constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 
 bool welch_supported(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
+hipError_t launch_fused1024(const FusedBatch &b, const float *win, hipStream_t s);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_reduce(const RedBatch &b, hipStream_t s);
 hipError_t launch_tail(const TailBatch &b, hipStream_t s);

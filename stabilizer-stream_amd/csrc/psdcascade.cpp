@@ -367,112 +367,200 @@ int advance_round(psdc_handle *h, bool *did_work)
             }
     }
 
-    // share the persistent workgroups among the spans so that every workgroup
-    // walks about the same number of tiles
-    const size_t per_block = (tiles_total + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS;
-    auto blocks_for = [&](uint64_t ntiles) -> int { return (int)((ntiles + per_block - 1) / per_block); };
+    // ---- turn the work into kernel jobs ---------------------------------
+    // Fast path (fused1024_kernel): whole segment pairs of an N = 1024 Hann stream with
+    // Detrend::None and plain-sum averaging, 16-byte aligned.  Everything else -- other N,
+    // detrend, EWMA, an odd last segment, the decimator ranges a pair does not cover (the
+    // first segment of a stream is decimated whole, src/psd.rs:235-238; zero-copy seams) --
+    // goes through the generic welch / hbf_dec8 kernels.  Both write the same partial slab
+    // and next-stage stream, so the reduce and the bookkeeping do not care which ran.
+    struct PlanFused { FusedJob j; size_t work; };
+    struct PlanSeg { SegJob j; size_t work; };
+    std::vector<PlanFused> fjobs;
+    std::vector<PlanSeg> sjobs;
+    std::vector<DecJob> djobs;
+    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN && h->detrend == PSDC_DETREND_NONE;
+    uint64_t prof_samples = 0, prof_samples0 = 0;
+    for (size_t wi = 0; wi < works.size(); ++wi) {
+        Work &w = works[wi];
+        Channel &c = h->ch[w.c];
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        StageState *nx = t_next > 0 ? &c.st[w.k + 1] : nullptr;
+        const uint64_t nx_base = nx ? kf_after(w.c, w.k + 1) : 0;
+        auto add_dec = [&](const Span &sp, uint64_t ma, uint64_t mb) {
+            if (mb <= ma || mb <= g.drain || !nx)
+                return;
+            DecJob dj{};
+            dj.src = sp.src;
+            dj.src_base = (long long)sp.src_base;
+            dj.m0 = (long long)ma;
+            dj.dst = nx->buf.p[nx->buf.cur ^ 1];
+            dj.dst_base = (long long)nx_base;
+            dj.nout = (int)(mb - ma);
+            djobs.push_back(dj);
+        };
+        auto add_seg = [&](const Span &sp, uint64_t sa, uint64_t sb) {
+            if (sb <= sa)
+                return;
+            SegJob sj{};
+            sj.src = sp.src;
+            sj.src_base = (long long)sp.src_base;
+            sj.seg0 = (long long)sa;
+            sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                              : -std::numeric_limits<double>::infinity();
+            sj.nseg = (int)(sb - sa);
+            sj.ntiles = (int)((sb - sa + spt - 1) / spt);
+            sj.step0 = (int)(sa - w.j_old) + 1;
+            sj.nb = (int)w.ew.nb;
+            sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+            sj.ewma = w.ew.ewma ? 1 : 0;
+            sjobs.push_back({sj, wi});
+        };
+        for (int i = 0; i < w.nspans; ++i) {
+            const Span &sp = w.spans[i];
+            uint64_t np = (fast_ok && !w.ew.ewma && nx) ? (sp.seg_b - sp.seg_a) / 2 : 0;
+            const float *fsrc = sp.src + (g.hop * sp.seg_a - sp.src_base);
+            const uint64_t mf0 = 64 * (sp.seg_a + 1), mf1 = mf0 + 128 * np;
+            if (np && ((reinterpret_cast<uintptr_t>(fsrc) & 15u) != 0 || mf0 < sp.m_a || mf1 > sp.m_b))
+                np = 0;
+            if (np) {
+                FusedJob fj{};
+                fj.src = fsrc;
+                fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
+                fj.npairs = (int)np;
+                fj.run = (int)std::min<uint64_t>(FUSED_MAX_RUN, std::max<uint64_t>(1, (np + 511) / 512));
+                fjobs.push_back({fj, wi});
+                add_seg(sp, sp.seg_a + 2 * np, sp.seg_b);
+                add_dec(sp, sp.m_a, mf0);
+                add_dec(sp, mf1, sp.m_b);
+            } else {
+                add_seg(sp, sp.seg_a, sp.seg_b);
+                add_dec(sp, sp.m_a, sp.m_b);
+            }
+        }
+        prof_samples += w.p_new - w.p_old;
+        if (w.k == 0)
+            prof_samples0 += w.p_new - w.p_old;
+    }
+
+    // share the persistent workgroups so that every workgroup walks about the same amount
+    size_t seg_tiles = 0, fused_tiles = 0;
+    for (auto &s : sjobs)
+        seg_tiles += (size_t)s.j.ntiles;
+    auto ftiles = [](const FusedJob &j) { return (size_t)((j.npairs + FUSED_WAVES * j.run - 1) / (FUSED_WAVES * j.run)); };
+    for (auto &f : fjobs)
+        fused_tiles += ftiles(f.j);
+    const size_t seg_per = std::max<size_t>(1, (seg_tiles + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS);
+    const size_t fus_per = std::max<size_t>(1, (fused_tiles + FUSED_MAX_BLOCKS - 1) / FUSED_MAX_BLOCKS);
     size_t blocks_total = 0;
-    for (auto &w : works)
-        for (int i = 0; i < w.nspans; ++i)
-            blocks_total += (size_t)blocks_for((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
+    for (auto &s : sjobs) {
+        s.j.nblocks = (int)(((size_t)s.j.ntiles + seg_per - 1) / seg_per);
+        blocks_total += (size_t)s.j.nblocks;
+    }
+    for (auto &f : fjobs) {
+        f.j.nblocks = (int)((ftiles(f.j) + fus_per - 1) / fus_per);
+        blocks_total += (size_t)f.j.nblocks;
+    }
     int rc = ensure_partial(h, blocks_total * h->n);
     if (rc)
         return rc;
-
-    // welch + reduce, at most MAX_JOBS spans per launch
-    size_t slab = 0; // floats used in d_partial
-    size_t wi = 0;
-    while (wi < works.size()) {
-        WelchBatch wb{};
-        RedBatch rb{};
-        wb.hop = (int)g.hop;
-        wb.detrend = h->detrend;
-        rb.n = (int)h->n;
-        uint64_t samples = 0, samples0 = 0;
-        while (wi < works.size() && wb.njobs + works[wi].nspans <= MAX_JOBS) {
-            const Work &w = works[wi];
-            StageState &s = h->ch[w.c].st[w.k];
-            RedJob rj{};
+    // slab: the partials of one work are contiguous (fused first, then generic)
+    std::vector<RedJob> rjobs(works.size());
+    {
+        size_t slab = 0, fi = 0, si = 0;
+        for (size_t wi = 0; wi < works.size(); ++wi) {
+            RedJob &rj = rjobs[wi];
             rj.partial = h->d_partial + slab;
-            rj.spectrum = s.spectrum;
-            rj.g_total = (float)w.ew.g_total;
-            for (int i = 0; i < w.nspans; ++i) {
-                const Span &sp = w.spans[i];
-                const uint64_t nseg = sp.seg_b - sp.seg_a;
-                if (nseg == 0)
-                    continue;
-                SegJob &sj = wb.jobs[wb.njobs++];
-                sj.src = sp.src;
-                sj.src_base = (long long)sp.src_base;
-                sj.seg0 = (long long)sp.seg_a;
-                sj.partial = h->d_partial + slab;
-                sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
-                                                  : -std::numeric_limits<double>::infinity();
-                sj.nseg = (int)nseg;
-                sj.ntiles = (int)((nseg + spt - 1) / spt);
-                sj.nblocks = blocks_for((uint64_t)sj.ntiles);
-                sj.block_begin = wb.nblocks;
-                sj.step0 = (int)(sp.seg_a - w.j_old) + 1;
-                sj.nb = (int)w.ew.nb;
-                sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
-                sj.ewma = w.ew.ewma ? 1 : 0;
-                wb.nblocks += sj.nblocks;
-                rj.nparts += sj.nblocks;
-                slab += (size_t)sj.nblocks * h->n;
+            rj.spectrum = h->ch[works[wi].c].st[works[wi].k].spectrum;
+            rj.g_total = (float)works[wi].ew.g_total;
+            rj.nparts = 0;
+            for (; fi < fjobs.size() && fjobs[fi].work == wi; ++fi) {
+                fjobs[fi].j.partial = h->d_partial + slab;
+                slab += (size_t)fjobs[fi].j.nblocks * h->n;
+                rj.nparts += fjobs[fi].j.nblocks;
             }
-            rb.jobs[rb.njobs++] = rj;
-            const uint64_t ns = w.p_new - w.p_old;
-            samples += ns;
-            if (w.k == 0)
-                samples0 += ns;
-            ++wi;
+            for (; si < sjobs.size() && sjobs[si].work == wi; ++si) {
+                sjobs[si].j.partial = h->d_partial + slab;
+                slab += (size_t)sjobs[si].j.nblocks * h->n;
+                rj.nparts += sjobs[si].j.nblocks;
+            }
         }
         if (slab > h->partial_cap)
             return fail(h, PSDC_ERR_DEVICE, "internal: partial slab overflow");
-        ProfEvents pe{};
-        if (h->profile) {
-            HIPCHK(h, hipEventCreate(&pe.a));
-            HIPCHK(h, hipEventCreate(&pe.b));
-            HIPCHK(h, hipEventRecord(pe.a, h->stream));
-        }
-        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
-        if (h->profile) {
-            HIPCHK(h, hipEventRecord(pe.b, h->stream));
-            h->prof_pending.push_back(pe);
-            h->prof.launches += 1;
-            h->prof.samples += samples;
-            h->prof.stage0_samples += samples0;
-        }
-        HIPCHK(h, launch_reduce(rb, h->stream));
     }
 
-    // decimator: this round's outputs are appended to the next-stage streams
-    {
+    // ---- launches: fused, generic welch, reduce, generic decimator -------
+    // HIP events bracket the dominant kernel of the round (fused when present)
+    const bool prof_fused = !fjobs.empty();
+    auto prof_begin = [&](ProfEvents &pe) -> int {
+        if (!h->profile)
+            return PSDC_OK;
+        HIPCHK(h, hipEventCreate(&pe.a));
+        HIPCHK(h, hipEventCreate(&pe.b));
+        HIPCHK(h, hipEventRecord(pe.a, h->stream));
+        return PSDC_OK;
+    };
+    auto prof_end = [&](ProfEvents &pe, bool first) -> int {
+        if (!h->profile)
+            return PSDC_OK;
+        HIPCHK(h, hipEventRecord(pe.b, h->stream));
+        h->prof_pending.push_back(pe);
+        h->prof.launches += 1;
+        if (first) {
+            h->prof.samples += prof_samples;
+            h->prof.stage0_samples += prof_samples0;
+        }
+        return PSDC_OK;
+    };
+    for (size_t i = 0; i < fjobs.size();) {
+        FusedBatch fb{};
+        for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
+            FusedJob j = fjobs[i].j;
+            j.block_begin = fb.nblocks;
+            fb.nblocks += j.nblocks;
+            fb.jobs[fb.njobs++] = j;
+        }
+        ProfEvents pe{};
+        const bool first = (i <= (size_t)MAX_JOBS);
+        if ((rc = prof_begin(pe)))
+            return rc;
+        HIPCHK(h, launch_fused1024(fb, h->d_win, h->stream));
+        if ((rc = prof_end(pe, first)))
+            return rc;
+    }
+    for (size_t i = 0; i < sjobs.size();) {
+        WelchBatch wb{};
+        wb.hop = (int)g.hop;
+        wb.detrend = h->detrend;
+        for (; i < sjobs.size() && wb.njobs < MAX_JOBS; ++i) {
+            SegJob j = sjobs[i].j;
+            j.block_begin = wb.nblocks;
+            wb.nblocks += j.nblocks;
+            wb.jobs[wb.njobs++] = j;
+        }
+        ProfEvents pe{};
+        const bool first = (i <= (size_t)MAX_JOBS);
+        if (!prof_fused && (rc = prof_begin(pe)))
+            return rc;
+        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
+        if (!prof_fused && (rc = prof_end(pe, first)))
+            return rc;
+    }
+    for (size_t i = 0; i < rjobs.size();) {
+        RedBatch rb{};
+        rb.n = (int)h->n;
+        for (; i < rjobs.size() && rb.njobs < MAX_JOBS; ++i)
+            rb.jobs[rb.njobs++] = rjobs[i];
+        HIPCHK(h, launch_reduce(rb, h->stream));
+    }
+    for (size_t i = 0; i < djobs.size();) {
         DecBatch db{};
         db.drain = (int)g.drain;
-        for (auto &w : works) {
-            Channel &c = h->ch[w.c];
-            for (int i = 0; i < w.nspans; ++i) {
-                const Span &sp = w.spans[i];
-                const uint64_t nout = sp.m_b - sp.m_a;
-                if (nout == 0 || sp.m_b <= g.drain)
-                    continue; // nothing reaches the next stage yet
-                if (db.njobs == MAX_JOBS) {
-                    HIPCHK(h, launch_dec(db, h->stream));
-                    db = DecBatch{};
-                    db.drain = (int)g.drain;
-                }
-                StageState &nx = c.st[w.k + 1];
-                DecJob &dj = db.jobs[db.njobs++];
-                dj.src = sp.src;
-                dj.src_base = (long long)sp.src_base;
-                dj.m0 = (long long)sp.m_a;
-                dj.dst = nx.buf.p[nx.buf.cur ^ 1];
-                dj.dst_base = (long long)kf_after(w.c, w.k + 1);
-                dj.nout = (int)nout;
-                dj.tile_begin = db.ntiles;
-                db.ntiles += (int)((nout + DEC_TILE - 1) / DEC_TILE);
-            }
+        for (; i < djobs.size() && db.njobs < MAX_JOBS; ++i) {
+            DecJob j = djobs[i];
+            j.tile_begin = db.ntiles;
+            db.ntiles += (j.nout + DEC_TILE - 1) / DEC_TILE;
+            db.jobs[db.njobs++] = j;
         }
         HIPCHK(h, launch_dec(db, h->stream));
     }

@@ -4,7 +4,9 @@
 // (ds_read_b64: two 32-lane groups, 64 banks x 4 B; ds_write_b64: four
 // 16-lane groups, 32 banks x 4 B).  Build: g++ -O2 -std=c++17 -I<csrc>.
 #include "fft_core.h"
+#include "fft_wave1024.h"
 #include <cmath>
+#include <algorithm>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -133,6 +135,89 @@ static int check(bool rotate)
     return (seen == N && err < 2e-6) ? 0 : 1;
 }
 
+// the wave-level (4,16,16) FFT of the fused kernel
+static int check_wave1024()
+{
+    using namespace w1024;
+    std::vector<cf> z(N), frame(N), tw0(TW0_SIZE), tw1(TW1_SIZE);
+    srand(99);
+    for (int i = 0; i < N; ++i) {
+        z[i].re = (float)rand() / RAND_MAX - 0.5f;
+        z[i].im = (float)rand() / RAND_MAX - 0.5f;
+    }
+    for (int q = 1; q < 4; ++q)
+        for (int s = 0; s < 256; ++s) {
+            double a = -2.0 * M_PI * (double)(s * q) / 1024.0;
+            tw0[(q - 1) * 256 + s] = {(float)cos(a), (float)sin(a)};
+        }
+    for (int q = 1; q < 16; ++q)
+        for (int s = 0; s < 16; ++s) {
+            double a = -2.0 * M_PI * (double)(s * q) / 256.0;
+            tw1[(q - 1) * 16 + s] = {(float)cos(a), (float)sin(a)};
+        }
+    std::vector<std::vector<cf>> regs(64, std::vector<cf>(16));
+    for (int t = 0; t < 64; ++t)
+        for (int m = 0; m < 4; ++m)
+            for (int c = 0; c < 4; ++c)
+                regs[t][4 * m + c] = z[4 * t + c + 256 * m];
+    for (int t = 0; t < 64; ++t) pass0(t, regs[t].data(), tw0.data());
+    for (int t = 0; t < 64; ++t) store0(t, regs[t].data(), frame.data());
+    for (int t = 0; t < 64; ++t) load1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < 64; ++t) pass1(t, regs[t].data(), tw1.data());
+    for (int t = 0; t < 64; ++t) store1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < 64; ++t) load2(t, regs[t].data(), frame.data());
+    for (int t = 0; t < 64; ++t) pass2(regs[t].data());
+    // conflicts
+    long rd = 0, rdi = 0, wr = 0, wri = 0;
+    for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 4; ++c)
+            for (int g = 0; g < 4; ++g) {
+                std::vector<int> sl;
+                for (int t = 16 * g; t < 16 * g + 16; ++t) sl.push_back(swz(256 * q + 4 * t + c));
+                wr += group_cycles(sl, 16), ++wri;
+            }
+    for (int m = 0; m < 16; ++m) {
+        for (int g = 0; g < 2; ++g) {
+            std::vector<int> a, b;
+            for (int t = 32 * g; t < 32 * g + 32; ++t) {
+                a.push_back(swz(256 * (t >> 4) + (t & 15) + 16 * m));
+                b.push_back(swz(16 * t + m));
+            }
+            rd += group_cycles(a, 32) + group_cycles(b, 32), rdi += 2;
+        }
+        for (int g = 0; g < 4; ++g) {
+            std::vector<int> a;
+            for (int t = 16 * g; t < 16 * g + 16; ++t) a.push_back(swz(256 * (t >> 4) + (t & 15) + 16 * m));
+            wr += group_cycles(a, 16), ++wri;
+        }
+    }
+    std::vector<std::complex<double>> w(N);
+    for (int i = 0; i < N; ++i) w[i] = std::polar(1.0, -2.0 * M_PI * i / N);
+    std::vector<double> got(N, -1.0);
+    double err = 0, pmax = 0;
+    std::vector<double> pw(N);
+    for (int k = 0; k < N; ++k) {
+        std::complex<double> acc = 0;
+        for (int j = 0; j < N; ++j)
+            acc += std::complex<double>(z[j].re, z[j].im) * w[(int)(((long)j * k) % N)];
+        pw[k] = std::norm(acc);
+        pmax = std::max(pmax, pw[k]);
+    }
+    for (int t = 0; t < 64; ++t)
+        for (int q = 0; q < 16; ++q) {
+            int k = freq_of(t, q);
+            if (k < 0 || k >= N || got[k] >= 0) {
+                printf("wave1024: bad/duplicate k=%d\n", k);
+                return 1;
+            }
+            got[k] = (double)regs[t][q].re * regs[t][q].re + (double)regs[t][q].im * regs[t][q].im;
+        }
+    for (int k = 0; k < N; ++k) err = std::max(err, fabs(got[k] - pw[k]) / pmax);
+    printf("wave1024 (4,16,16): max|dP|/Pmax=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
+           err, rd, rdi, wr, wri);
+    return (err < 2e-6 && rd == rdi && wr == wri) ? 0 : 1;
+}
+
 int main()
 {
     int bad = 0;
@@ -148,6 +233,7 @@ int main()
     bad |= check<4096>(false);
     bad |= check<8192>(false);
     bad |= check<16384>(false);
+    bad |= check_wave1024();
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }
