@@ -9,8 +9,11 @@
 // after pass 2:  k = (t >> 4) + 4 (t & 15) + 64 q.
 // Only |X|^2 is consumed downstream (src/psd.rs:228-233).
 //
-// The frame swizzle makes every 8-byte LDS access of every pass bank-conflict
-// free under the gfx950 rules (tests/host/fft_emul.cpp counts them).
+// The frame is padded by one element per 16 (physical = idx + idx/16, 1088
+// elements per wave).  That makes every 8-byte LDS access of every pass
+// bank-conflict free under the gfx950 rules (tests/host/fft_emul.cpp counts
+// them) AND keeps every address of a pass of the form lane_base + constant,
+// so the constants ride in the DS instruction's offset field.
 #pragma once
 #include "fft_core.h"
 
@@ -21,7 +24,9 @@ constexpr int N = 1024;
 constexpr int TW0_SIZE = 3 * 256; // W_1024^(s q), q = 1..3, s < 256
 constexpr int TW1_SIZE = 15 * 16; // W_256^(s q),  q = 1..15, s < 16
 
-PSDK_HD int swz(int idx) { return idx ^ ((idx >> 4) & 3) ^ (((idx >> 6) & 7) << 2); }
+constexpr int FRAME = N + N / 16; // padded frame, complex elements
+
+PSDK_HD int swz(int idx) { return idx + (idx >> 4); }
 
 PSDK_HD int freq_of(int t, int q) { return (t >> 4) + 4 * (t & 15) + 64 * q; }
 
@@ -44,20 +49,21 @@ PSDK_HD void pass0(int t, cf *v, const cf *tw0)
 
 PSDK_HD void store0(int t, const cf *v, cf *frame)
 {
+    cf *base = frame + (4 * t + (t >> 2)); // swz(256 q + 4 t + c) = base + 272 q + c
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            frame[swz(256 * q + 4 * t + c)] = v[4 * q + c];
+            base[272 * q + c] = v[4 * q + c];
 }
 
 // pass 1: sub-transforms of length 256 (b = t >> 4), stride 16 (s = t & 15)
 PSDK_HD void load1(int t, cf *v, const cf *frame)
 {
-    const int base = 256 * (t >> 4) + (t & 15);
+    const cf *base = frame + (272 * (t >> 4) + (t & 15)); // swz(256 b + s + 16 m) = base + 17 m
 #pragma unroll
     for (int m = 0; m < 16; ++m)
-        v[m] = frame[swz(base + 16 * m)];
+        v[m] = base[17 * m];
 }
 
 // tw1[(q-1)*16 + s] = W_256^(s q)
@@ -72,18 +78,19 @@ PSDK_HD void pass1(int t, cf *v, const cf *tw1)
 
 PSDK_HD void store1(int t, const cf *v, cf *frame)
 {
-    const int base = 256 * (t >> 4) + (t & 15);
+    cf *base = frame + (272 * (t >> 4) + (t & 15));
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        frame[swz(base + 16 * q)] = v[q];
+        base[17 * q] = v[q];
 }
 
 // pass 2: 16 consecutive elements per lane
 PSDK_HD void load2(int t, cf *v, const cf *frame)
 {
+    const cf *base = frame + 17 * t; // swz(16 t + m) = 17 t + m
 #pragma unroll
     for (int m = 0; m < 16; ++m)
-        v[m] = frame[swz(16 * t + m)];
+        v[m] = base[m];
 }
 
 PSDK_HD void pass2(cf *v) { Dft<16>::run(v); }

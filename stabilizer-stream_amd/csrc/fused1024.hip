@@ -23,7 +23,7 @@ constexpr int NX = 1024 + HBF_HALO;          // 1312 stage inputs per pair
 constexpr int NA = 512 + HBF_PRE_A;          // 650 A outputs
 constexpr int NB = 256 + HBF_PRE_B;          // 314 B outputs
 constexpr int X_SKIP = 512 - HBF_HALO;       // 224: first needed sample of the older chunk
-// scratch layout (floats), 2048 per wave
+// scratch layout (floats) inside the wave's 2176-float frame
 constexpr int XE = 0, XO = NX / 2;           // 656 each
 constexpr int AE = NX, AO = NX + 328;        // 325 each (NA / 2)
 constexpr int BE = 0, BO = 160;              // 157 each (NB / 2), overlays XE once A is done
@@ -38,6 +38,21 @@ constexpr int C_CE = C_D - HBF_MC + 1, C_CO = C_D - 2 * HBF_MC + 1; // 15, 0
 static_assert(A_CO == 1 && B_CO == 0 && C_CO == 0 && (A_CE % 2) == 0 && (B_CE % 2) == 0 && (C_CE % 2) == 1,
               "the aligned 8-byte read pattern below assumes these offsets");
 } // namespace f1024
+
+// pass 0 with the twiddles laid out [q][c][lane] so that a wavefront reads consecutive
+// 8-byte words (conflict free): tw0t[((q-1)*4 + c)*64 + t] = W_1024^((4t + c) q)
+__device__ __forceinline__ void pass0_t(int t, cf *v, const cf *tw0t)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cf b[4] = {v[c], v[4 + c], v[8 + c], v[12 + c]};
+        Dft<4>::run(b);
+        v[c] = b[0];
+        v[4 + c] = cmul(b[1], tw0t[(0 * 4 + c) * 64 + t]);
+        v[8 + c] = cmul(b[2], tw0t[(1 * 4 + c) * 64 + t]);
+        v[12 + c] = cmul(b[3], tw0t[(2 * 4 + c) * 64 + t]);
+    }
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -90,25 +105,29 @@ __device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const floa
     y1 = e1 + a1;
 }
 
-__global__ __launch_bounds__(FUSED_WAVES * 64, 2) void fused1024_kernel(const FusedBatch batch,
+__global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES_PER_SIMD) void fused1024_kernel(const FusedBatch batch,
                                                                        const float *__restrict__ win)
 {
     using namespace w1024;
     using namespace f1024;
-    __shared__ cf s_frames[FUSED_WAVES * N];
+    __shared__ cf s_frames[FUSED_WAVES * FRAME];
     __shared__ cf s_tw0[TW0_SIZE];
     __shared__ cf s_tw1[TW1_SIZE];
+    __shared__ float4 s_win[256]; // window, float4 piece m of lane t at [64 m + t]
 
     const int tid = threadIdx.x;
     const int t = tid & 63, wv = tid >> 6;
 
     // twiddle tables: W_1024^(s q) and W_256^(s q) (sincospi keeps them exact to f32 rounding)
     for (int i = tid; i < TW0_SIZE; i += FUSED_WAVES * 64) {
-        const int q = i / 256 + 1, s = i % 256;
+        const int q = i / 256 + 1, c = (i / 64) & 3, l = i & 63; // [q][c][lane]
+        const int s = 4 * l + c;
         float sn, cs;
         sincospif(-2.0f * (float)((s * q) & 1023) / 1024.0f, &sn, &cs);
         s_tw0[i] = {cs, sn};
     }
+    for (int i = tid; i < 256; i += FUSED_WAVES * 64)
+        s_win[i] = *reinterpret_cast<const float4 *>(win + 4 * i); // (src/psd.rs:44-48 table)
     for (int i = tid; i < TW1_SIZE; i += FUSED_WAVES * 64) {
         const int q = i / 16 + 1, s = i % 16;
         float sn, cs;
@@ -125,19 +144,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void fused1024_kernel(const Fu
     const int tile_pairs = FUSED_WAVES * run;
     const int ntiles = (npairs + tile_pairs - 1) / tile_pairs;
 
-    cf *frame = s_frames + wv * N;
+    cf *frame = s_frames + wv * FRAME;
     float *sf = reinterpret_cast<float *>(frame);
 
-    // window of this lane's 16 FFT inputs n = 4t + c + 256m (src/psd.rs:44-48 table)
-    float wn[16];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const float4 w4 = *reinterpret_cast<const float4 *>(win + 256 * m + 4 * t);
-        wn[4 * m + 0] = w4.x;
-        wn[4 * m + 1] = w4.y;
-        wn[4 * m + 2] = w4.z;
-        wn[4 * m + 3] = w4.w;
-    }
     const float ta[HBF_MA] = {PSDK_HBF_TAPS_A};
     const float tb[HBF_MB] = {PSDK_HBF_TAPS_B};
     const float tc[HBF_MC] = {PSDK_HBF_TAPS_C};
@@ -149,116 +158,125 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void fused1024_kernel(const Fu
 
     __syncthreads(); // twiddle tables ready
 
+    // One pair p: decimate its 1024 new samples, FFT it, accumulate.  Register groups of two
+    // float4 each: lo/up = lower/upper half of chunk p, nl = lower half of chunk p + 1 (the
+    // upper half of chunk p + 1 is not needed by pair p).  Once lo/up have been windowed into
+    // the FFT registers they are dead: the upper half of chunk p + 1 is loaded into `up` and
+    // the lower half of chunk p + 2 into `lo`, in flight during the FFT passes.  For pair
+    // p + 1 the roles are (lo, up, nl) <- (nl, up, lo).
+    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool more,
+                         float *o) {
+        // ---- decimator: inputs rel r = 0..1311 <-> src[1024 p + 224 + r] ----
+        if (t >= X_SKIP / 4) {
+            const int h = 2 * (t - X_SKIP / 4);
+            *reinterpret_cast<f2 *>(sf + XE + h) = {lo[0].x, lo[0].z};
+            *reinterpret_cast<f2 *>(sf + XO + h) = {lo[0].y, lo[0].w};
+        }
+        {
+            const float4 c1 = lo[1], c2 = up[0], c3 = up[1], n0 = nl[0], n1 = nl[1];
+            const int h = 2 * t - X_SKIP / 2;
+            *reinterpret_cast<f2 *>(sf + XE + h + 128) = {c1.x, c1.z};
+            *reinterpret_cast<f2 *>(sf + XO + h + 128) = {c1.y, c1.w};
+            *reinterpret_cast<f2 *>(sf + XE + h + 256) = {c2.x, c2.z};
+            *reinterpret_cast<f2 *>(sf + XO + h + 256) = {c2.y, c2.w};
+            *reinterpret_cast<f2 *>(sf + XE + h + 384) = {c3.x, c3.z};
+            *reinterpret_cast<f2 *>(sf + XO + h + 384) = {c3.y, c3.w};
+            *reinterpret_cast<f2 *>(sf + XE + h + 512) = {n0.x, n0.z};
+            *reinterpret_cast<f2 *>(sf + XO + h + 512) = {n0.y, n0.w};
+            *reinterpret_cast<f2 *>(sf + XE + h + 640) = {n1.x, n1.z};
+            *reinterpret_cast<f2 *>(sf + XO + h + 640) = {n1.y, n1.w};
+        }
+        wave_sync();
+        for (int u = t; u < NA / 2; u += 64) { // stage A: outputs 2u, 2u+1 -> AE[u], AO[u]
+            float y0, y1;
+            hbf_two<HBF_MA, A_CE, A_CO>(sf + XE, sf + XO, 2 * u, ta, y0, y1);
+            sf[AE + u] = y0;
+            sf[AO + u] = y1;
+        }
+        wave_sync();
+        for (int u = t; u < NB / 2; u += 64) { // stage B
+            float y0, y1;
+            hbf_two<HBF_MB, B_CE, B_CO>(sf + AE, sf + AO, 2 * u, tb, y0, y1);
+            sf[BE + u] = y0;
+            sf[BO + u] = y1;
+        }
+        wave_sync();
+        { // stage C: 128 outputs, two per lane
+            float y0, y1;
+            hbf_two<HBF_MC, C_CE, C_CO>(sf + BE, sf + BO, 2 * t, tc, y0, y1);
+            o[2 * t] = y0;
+            o[2 * t + 1] = y1;
+        }
+        wave_sync(); // scratch is reused by the FFT
+
+        // ---- FFT of the pair: re = segment 2p, im = segment 2p + 1 ----
+        cf v[16];
+        {
+            const float4 w0 = s_win[t], w1 = s_win[64 + t], w2 = s_win[128 + t], w3 = s_win[192 + t];
+            const float4 a0 = lo[0], a1 = lo[1], a2 = up[0], a3 = up[1], b2 = nl[0], b3 = nl[1];
+            v[0] = {a0.x * w0.x, a2.x * w0.x};
+            v[1] = {a0.y * w0.y, a2.y * w0.y};
+            v[2] = {a0.z * w0.z, a2.z * w0.z};
+            v[3] = {a0.w * w0.w, a2.w * w0.w};
+            v[4] = {a1.x * w1.x, a3.x * w1.x};
+            v[5] = {a1.y * w1.y, a3.y * w1.y};
+            v[6] = {a1.z * w1.z, a3.z * w1.z};
+            v[7] = {a1.w * w1.w, a3.w * w1.w};
+            v[8] = {a2.x * w2.x, b2.x * w2.x};
+            v[9] = {a2.y * w2.y, b2.y * w2.y};
+            v[10] = {a2.z * w2.z, b2.z * w2.z};
+            v[11] = {a2.w * w2.w, b2.w * w2.w};
+            v[12] = {a3.x * w3.x, b3.x * w3.x};
+            v[13] = {a3.y * w3.y, b3.y * w3.y};
+            v[14] = {a3.z * w3.z, b3.z * w3.z};
+            v[15] = {a3.w * w3.w, b3.w * w3.w};
+        }
+        if (more) { // pair p + 1 exists: chunk p + 1 upper -> up, chunk p + 2 lower -> lo
+            up[0] = cnext[128];
+            up[1] = cnext[192];
+            lo[0] = cnext[256];
+            lo[1] = cnext[256 + 64];
+        }
+        pass0_t(t, v, s_tw0);
+        store0(t, v, frame);
+        wave_sync();
+        load1(t, v, frame);
+        pass1(t, v, s_tw1);
+        wave_sync();
+        store1(t, v, frame);
+        wave_sync();
+        load2(t, v, frame);
+        pass2(v);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+        wave_sync(); // next pair's decimator writes the scratch
+    };
+
     for (int tile = wb; tile < ntiles; tile += job.nblocks) {
         const int p0 = tile * tile_pairs + wv * run;
         const int p1 = min(npairs, p0 + run);
         if (p0 >= p1)
             continue; // wave-uniform
-        // chunk q = src[1024 q ..): lane holds float4 pieces m = 0..3 at 256 m + 4 t.
-        // The upper half (m = 2, 3) of chunk q exists only if pair q exists.
+        // chunk c = src[1024 c ..): lane holds float4 pieces m = 0..3 at 256 m + 4 t; pair p needs
+        // chunk p and the lower half (m = 0, 1) of chunk p + 1, which is all a job guarantees.
         const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * 256 + t;
-        float4 cur[4], nxt[4], pre[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            cur[m] = cp[64 * m];
-        nxt[0] = cp[256 + 0];
-        nxt[1] = cp[256 + 64];
-        if (p0 + 1 < npairs) {
-            nxt[2] = cp[256 + 128];
-            nxt[3] = cp[256 + 192];
-        } else {
-            nxt[2] = nxt[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int p = p0; p < p1; ++p) {
-            // prefetch chunk p + 2 for the next pair of this run
+        float4 ga[2], gb[2], gc[2];
+        ga[0] = cp[0];
+        ga[1] = cp[64];
+        gb[0] = cp[128];
+        gb[1] = cp[192];
+        gc[0] = cp[256];
+        gc[1] = cp[256 + 64];
+        float *o = job.dst + (size_t)p0 * 128;
+        for (int p = p0; p < p1; p += 2) {
+            pair_step(ga, gb, gc, cp + 256, p + 1 < p1, o);
+            cp += 256;
+            o += 128;
             if (p + 1 < p1) {
-                const float4 *np = cp + (size_t)(p - p0 + 2) * 256;
-                pre[0] = np[0];
-                pre[1] = np[64];
-                if (p + 2 < npairs) {
-                    pre[2] = np[128];
-                    pre[3] = np[192];
-                } else {
-                    pre[2] = pre[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-
-            // ---- decimator: inputs rel r = 0..1311 <-> src[1024 p + 224 + r] ----
-            // r of a float4 piece: cur m: 256 m + 4 t - 224; nxt m: 1024 + 256 m + 4 t - 224
-            if (t >= X_SKIP / 4) {
-                const int h = 2 * (t - X_SKIP / 4);
-                *reinterpret_cast<f2 *>(sf + XE + h) = {cur[0].x, cur[0].z};
-                *reinterpret_cast<f2 *>(sf + XO + h) = {cur[0].y, cur[0].w};
-            }
-#pragma unroll
-            for (int m = 1; m < 4; ++m) {
-                const int h = (256 * m - X_SKIP) / 2 + 2 * t;
-                *reinterpret_cast<f2 *>(sf + XE + h) = {cur[m].x, cur[m].z};
-                *reinterpret_cast<f2 *>(sf + XO + h) = {cur[m].y, cur[m].w};
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int h = (1024 + 256 * m - X_SKIP) / 2 + 2 * t;
-                *reinterpret_cast<f2 *>(sf + XE + h) = {nxt[m].x, nxt[m].z};
-                *reinterpret_cast<f2 *>(sf + XO + h) = {nxt[m].y, nxt[m].w};
-            }
-            wave_sync();
-            // stage A: outputs j = 2u, 2u+1 -> AE[u], AO[u]
-            for (int u = t; u < NA / 2; u += 64) {
-                float y0, y1;
-                hbf_two<HBF_MA, A_CE, A_CO>(sf + XE, sf + XO, 2 * u, ta, y0, y1);
-                sf[AE + u] = y0;
-                sf[AO + u] = y1;
-            }
-            wave_sync();
-            // stage B
-            for (int u = t; u < NB / 2; u += 64) {
-                float y0, y1;
-                hbf_two<HBF_MB, B_CE, B_CO>(sf + AE, sf + AO, 2 * u, tb, y0, y1);
-                sf[BE + u] = y0;
-                sf[BO + u] = y1;
-            }
-            wave_sync();
-            // stage C: 128 outputs, two per lane
-            {
-                float y0, y1;
-                hbf_two<HBF_MC, C_CE, C_CO>(sf + BE, sf + BO, 2 * t, tc, y0, y1);
-                float *o = job.dst + (size_t)p * 128 + 2 * t;
-                o[0] = y0;
-                o[1] = y1;
-            }
-            wave_sync(); // scratch is reused by the FFT
-
-            // ---- FFT of the pair: re = segment 2p, im = segment 2p + 1 ----
-            cf v[16];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 a = cur[m];
-                const float4 b = (m < 2) ? cur[m + 2] : nxt[m - 2];
-                v[4 * m + 0] = {a.x * wn[4 * m + 0], b.x * wn[4 * m + 0]};
-                v[4 * m + 1] = {a.y * wn[4 * m + 1], b.y * wn[4 * m + 1]};
-                v[4 * m + 2] = {a.z * wn[4 * m + 2], b.z * wn[4 * m + 2]};
-                v[4 * m + 3] = {a.w * wn[4 * m + 3], b.w * wn[4 * m + 3]};
-            }
-            pass0(t, v, s_tw0);
-            store0(t, v, frame);
-            wave_sync();
-            load1(t, v, frame);
-            pass1(t, v, s_tw1);
-            wave_sync(); // all lanes have read before anyone overwrites in place
-            store1(t, v, frame);
-            wave_sync();
-            load2(t, v, frame);
-            pass2(v);
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
-            wave_sync(); // next pair's decimator writes the scratch
-
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                cur[m] = nxt[m];
-                nxt[m] = pre[m];
+                pair_step(gc, gb, ga, cp + 256, p + 2 < p1, o);
+                cp += 256;
+                o += 128;
             }
         }
     }
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void fused1024_kernel(const Fu
         float acc = 0.0f;
 #pragma unroll
         for (int g = 0; g < FUSED_WAVES; ++g)
-            acc += all[g * 2 * N + k];
+            acc += all[g * 2 * FRAME + k];
         out[k] = acc;
     }
 }

@@ -78,7 +78,7 @@ struct FusedJob {
     float *dst;         // where decimator output 64 (seg_a + 1) lands in the next stage's stream
     float *partial;     // [nblocks][1024]
     int npairs;
-    int run;            // pairs per wavefront run (tile = 8 waves x run pairs)
+    int run;            // consecutive pairs per wavefront (workgroup b owns pairs [b, b+1) * waves * run)
     int block_begin;
     int nblocks;
 };
@@ -89,9 +89,15 @@ struct FusedBatch {
     FusedJob jobs[MAX_JOBS];
 };
 
-constexpr int FUSED_WAVES = 8;        // wavefronts per workgroup
-constexpr int FUSED_MAX_RUN = 8;      // pairs per wavefront run
-constexpr int FUSED_MAX_BLOCKS = 512; // 2 workgroups per CU
+#ifndef PSDK_FUSED_WAVES
+#define PSDK_FUSED_WAVES 8
+#endif
+#ifndef PSDK_FUSED_WPS
+#define PSDK_FUSED_WPS 4
+#endif
+constexpr int FUSED_WAVES = PSDK_FUSED_WAVES;        // wavefronts per workgroup
+constexpr int FUSED_WAVES_PER_SIMD = PSDK_FUSED_WPS; // launch bound: wavefronts per SIMD
+constexpr int FUSED_MAX_BLOCKS = 512;   // 2 workgroups per CU (2 x 81792 B of LDS, 127 VGPRs)
 
 // Carry the unconsumed tail of a stream to the front of its other buffer.
 struct TailJob {

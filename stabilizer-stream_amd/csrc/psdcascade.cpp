@@ -286,7 +286,6 @@ int advance_round(psdc_handle *h, bool *did_work)
 
     // collect the work of this round from the totals as they stand now
     std::vector<Work> works;
-    size_t tiles_total = 0;
     for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
         Channel &c = h->ch[ci];
         for (uint32_t k = 0; k < c.st.size(); ++k) {
@@ -316,8 +315,6 @@ int advance_round(psdc_handle *h, bool *did_work)
             } else {
                 w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new};
             }
-            for (int i = 0; i < w.nspans; ++i)
-                tiles_total += (size_t)((w.spans[i].seg_b - w.spans[i].seg_a + spt - 1) / spt);
             works.push_back(w);
         }
     }
@@ -428,7 +425,6 @@ int advance_round(psdc_handle *h, bool *did_work)
                 fj.src = fsrc;
                 fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
                 fj.npairs = (int)np;
-                fj.run = (int)std::min<uint64_t>(FUSED_MAX_RUN, std::max<uint64_t>(1, (np + 511) / 512));
                 fjobs.push_back({fj, wi});
                 add_seg(sp, sp.seg_a + 2 * np, sp.seg_b);
                 add_dec(sp, sp.m_a, mf0);
@@ -444,21 +440,25 @@ int advance_round(psdc_handle *h, bool *did_work)
     }
 
     // share the persistent workgroups so that every workgroup walks about the same amount
-    size_t seg_tiles = 0, fused_tiles = 0;
+    size_t seg_tiles = 0;
     for (auto &s : sjobs)
         seg_tiles += (size_t)s.j.ntiles;
-    auto ftiles = [](const FusedJob &j) { return (size_t)((j.npairs + FUSED_WAVES * j.run - 1) / (FUSED_WAVES * j.run)); };
+    uint64_t fused_pairs = 0;
     for (auto &f : fjobs)
-        fused_tiles += ftiles(f.j);
+        fused_pairs += (uint64_t)f.j.npairs;
     const size_t seg_per = std::max<size_t>(1, (seg_tiles + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS);
-    const size_t fus_per = std::max<size_t>(1, (fused_tiles + FUSED_MAX_BLOCKS - 1) / FUSED_MAX_BLOCKS);
     size_t blocks_total = 0;
     for (auto &s : sjobs) {
         s.j.nblocks = (int)(((size_t)s.j.ntiles + seg_per - 1) / seg_per);
         blocks_total += (size_t)s.j.nblocks;
     }
     for (auto &f : fjobs) {
-        f.j.nblocks = (int)((ftiles(f.j) + fus_per - 1) / fus_per);
+        // workgroups in proportion to the pairs; every wavefront of a job gets the same run
+        const uint64_t np = (uint64_t)f.j.npairs;
+        const uint64_t share = std::max<uint64_t>(1, (np * FUSED_MAX_BLOCKS + fused_pairs / 2) / fused_pairs);
+        const uint64_t run = (np + share * FUSED_WAVES - 1) / (share * FUSED_WAVES);
+        f.j.run = (int)run;
+        f.j.nblocks = (int)((np + run * FUSED_WAVES - 1) / (run * FUSED_WAVES));
         blocks_total += (size_t)f.j.nblocks;
     }
     int rc = ensure_partial(h, blocks_total * h->n);

@@ -139,7 +139,7 @@ static int check(bool rotate)
 static int check_wave1024()
 {
     using namespace w1024;
-    std::vector<cf> z(N), frame(N), tw0(TW0_SIZE), tw1(TW1_SIZE);
+    std::vector<cf> z(N), frame(FRAME), tw0(TW0_SIZE), tw1(TW1_SIZE);
     srand(99);
     for (int i = 0; i < N; ++i) {
         z[i].re = (float)rand() / RAND_MAX - 0.5f;
