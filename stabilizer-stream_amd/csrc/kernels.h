@@ -120,8 +120,7 @@ bool welch_supported(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
 hipError_t launch_fused1024(const FusedBatch &b, const float *win, hipStream_t s);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
-hipError_t launch_reduce(const RedBatch &b, hipStream_t s);
-hipError_t launch_tail(const TailBatch &b, hipStream_t s);
+hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);
 // frames: device copy of n_frames frames of frame_size bytes (AdcDac, `batches`
 // batches each); dst[c] receives 8*batches*n_frames samples of trace c.

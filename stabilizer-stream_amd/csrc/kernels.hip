@@ -6,10 +6,10 @@
 //                     ride one complex FFT (re = segment j, im = segment j+1).
 //   hbf_dec8_kernel   the /8 half-band cascade (src/psd.rs:246-253) on blocks
 //                     with a recomputed halo, drain applied on store (:255-260).
-//   reduce_kernel     folds per-tile power partials into the stage accumulator
-//                     with the batch EWMA factor (src/psd.rs:218-233).
-//   tail/fill/adcdac  stream carry, synthetic noise, AdcDac payload decode
-//                     (src/de/data.rs:11-82).
+//   post_kernel       folds the per-workgroup power partials into the stage
+//                     accumulators with the batch EWMA factor (src/psd.rs:218-233)
+//                     and carries the stream tails, one launch per round.
+//   fill/adcdac       synthetic noise, AdcDac payload decode (src/de/data.rs:11-82).
 //
 // No MFMA: the path is FP32-VALU / LDS bound.  64-wide
 // wavefronts throughout; LDS frames are exchanged with 8-byte accesses.
@@ -317,13 +317,11 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
 
 constexpr int RED_BINS = 32, RED_SLICES = 32; // 1024 threads: 32 bins x 32 slices of the partial list
 
-__global__ __launch_bounds__(RED_BINS *RED_SLICES) void reduce_kernel(const RedBatch batch)
+__device__ __forceinline__ void reduce_body(const RedJob &job, int n, int xblk)
 {
     __shared__ double part[RED_SLICES][RED_BINS + 1];
-    const RedJob &job = batch.jobs[blockIdx.y];
-    const int n = batch.n;
     const int lane = threadIdx.x % RED_BINS, slice = threadIdx.x / RED_BINS;
-    const int k = blockIdx.x * RED_BINS + lane;
+    const int k = xblk * RED_BINS + lane;
     const bool live = k <= n / 2;
     double acc = 0.0; // f64 partial sums: the fold adds no rounding of its own
     if (live) {
@@ -344,10 +342,18 @@ __global__ __launch_bounds__(RED_BINS *RED_SLICES) void reduce_kernel(const RedB
     }
 }
 
-__global__ __launch_bounds__(256) void tail_kernel(const TailBatch batch)
+// One launch for the round's epilogue: workgroups [0, nred) fold the partials of the
+// (channel, stage) jobs, the rest carry the stream tails.  The two roles touch disjoint data.
+__global__ __launch_bounds__(RED_BINS *RED_SLICES) void post_kernel(const RedBatch red, const TailBatch tail,
+                                                                  int red_xblocks)
 {
-    const TailJob &job = batch.jobs[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < job.count; i += gridDim.x * 256)
+    const int nred = red.njobs * red_xblocks;
+    if ((int)blockIdx.x < nred) {
+        reduce_body(red.jobs[blockIdx.x / red_xblocks], red.n, blockIdx.x % red_xblocks);
+        return;
+    }
+    const TailJob &job = tail.jobs[blockIdx.x - nred];
+    for (int i = threadIdx.x; i < job.count; i += RED_BINS * RED_SLICES)
         job.dst[i] = job.src[i];
 }
 
@@ -459,26 +465,13 @@ hipError_t launch_dec(const DecBatch &b, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_reduce(const RedBatch &b, hipStream_t s)
+hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s)
 {
-    if (b.njobs <= 0)
+    const int xb = (red.n / 2 + 1 + RED_BINS - 1) / RED_BINS;
+    const int grid = red.njobs * xb + tail.njobs;
+    if (grid <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(reduce_kernel, dim3((b.n / 2 + 1 + RED_BINS - 1) / RED_BINS, b.njobs),
-                       dim3(RED_BINS * RED_SLICES), 0, s, b);
-    return hipGetLastError();
-}
-
-hipError_t launch_tail(const TailBatch &b, hipStream_t s)
-{
-    if (b.njobs <= 0)
-        return hipSuccess;
-    int mx = 0;
-    for (int i = 0; i < b.njobs; ++i)
-        mx = b.jobs[i].count > mx ? b.jobs[i].count : mx;
-    if (mx == 0)
-        return hipSuccess;
-    const int gx = (mx + 255) / 256 > 64 ? 64 : (mx + 255) / 256;
-    hipLaunchKernelGGL(tail_kernel, dim3(gx, b.njobs), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(post_kernel, dim3(grid), dim3(RED_BINS * RED_SLICES), 0, s, red, tail, xb);
     return hipGetLastError();
 }
 

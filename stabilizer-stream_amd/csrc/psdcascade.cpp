@@ -266,7 +266,10 @@ int advance_round(psdc_handle *h, bool *did_work)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
-    const uint64_t seam = (uint64_t)h->n + HBF_HALO;
+    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN && h->detrend == PSDC_DETREND_NONE;
+    // the seam must complete every segment that starts in the carried tail; on the fast path
+    // one more hop so that the tail side can end on a whole segment pair
+    const uint64_t seam = (uint64_t)h->n + std::max<uint64_t>(HBF_HALO, fast_ok ? g.hop : 0);
     *did_work = false;
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
@@ -304,10 +307,17 @@ int advance_round(psdc_handle *h, bool *did_work)
             const uint64_t m_old = w.p_old >> 3, m_new = w.p_new >> 3;
             if (k == 0 && c.has_span) {
                 const uint64_t first = c.span.first;
-                const uint64_t j_split =
+                uint64_t j_split =
                     std::min<uint64_t>(j_new, std::max<uint64_t>(w.j_old, (first + g.hop - 1) / g.hop));
-                const uint64_t m_split =
+                uint64_t m_split =
                     std::min<uint64_t>(m_new, std::max<uint64_t>(m_old, (first + HBF_HALO + 7) / 8));
+                if (fast_ok && !w.ew.ewma && w.j_old > 0 && ((j_split - w.j_old) & 1) && j_split < j_new &&
+                    (j_split + 2) * g.hop <= first + seam) {
+                    // fast path: give the tail side a whole number of segment pairs and exactly
+                    // their decimator outputs, so that neither side leaves work for the generic kernels
+                    j_split += 1;
+                    m_split = std::min<uint64_t>(m_new, (j_split + 1) * (g.hop / 8));
+                }
                 if (j_split > w.j_old || m_split > m_old)
                     w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_split, m_old, m_split};
                 if (j_new > j_split || m_new > m_split)
@@ -376,7 +386,6 @@ int advance_round(psdc_handle *h, bool *did_work)
     std::vector<PlanFused> fjobs;
     std::vector<PlanSeg> sjobs;
     std::vector<DecJob> djobs;
-    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN && h->detrend == PSDC_DETREND_NONE;
     uint64_t prof_samples = 0, prof_samples0 = 0;
     for (size_t wi = 0; wi < works.size(); ++wi) {
         Work &w = works[wi];
@@ -546,13 +555,6 @@ int advance_round(psdc_handle *h, bool *did_work)
         if (!prof_fused && (rc = prof_end(pe, first)))
             return rc;
     }
-    for (size_t i = 0; i < rjobs.size();) {
-        RedBatch rb{};
-        rb.n = (int)h->n;
-        for (; i < rjobs.size() && rb.njobs < MAX_JOBS; ++i)
-            rb.jobs[rb.njobs++] = rjobs[i];
-        HIPCHK(h, launch_reduce(rb, h->stream));
-    }
     for (size_t i = 0; i < djobs.size();) {
         DecBatch db{};
         db.drain = (int)g.drain;
@@ -584,42 +586,45 @@ int advance_round(psdc_handle *h, bool *did_work)
 
     // carry the small tail [keep_from, old total) of every stream that consumed or
     // received samples to the front of its other buffer, then swap
-    {
-        TailBatch tb{};
-        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
-            Channel &c = h->ch[ci];
-            for (uint32_t k = 0; k < c.st.size(); ++k) {
-                StageState &s = c.st[k];
-                const uint64_t kf = keep_from(g, s);
-                const uint64_t told = old_total[ci][k];
-                const bool received = s.total != told;
-                if (kf == s.buf.base && !received && s.buf.end == s.total)
-                    continue;
-                const bool span0 = (k == 0 && c.has_span);
-                const uint64_t cnt = told > kf ? told - kf : 0;
-                const float *src = nullptr;
-                if (span0 && kf >= c.span.first)
-                    src = c.span.d_x + (kf - c.span.first);
-                else if (span0)
-                    return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
-                else if (cnt)
-                    src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
-                if (s.total - kf > s.buf.cap)
-                    return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
-                const int other = s.buf.cur ^ 1;
-                if (cnt) {
-                    if (tb.njobs == MAX_JOBS) {
-                        HIPCHK(h, launch_tail(tb, h->stream));
-                        tb = TailBatch{};
-                    }
-                    tb.jobs[tb.njobs++] = {src, s.buf.p[other], (int)cnt};
-                }
-                s.buf.cur = other;
-                s.buf.base = kf;
-                s.buf.end = s.total;
-            }
+    std::vector<TailJob> tjobs;
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        Channel &c = h->ch[ci];
+        for (uint32_t k = 0; k < c.st.size(); ++k) {
+            StageState &s = c.st[k];
+            const uint64_t kf = keep_from(g, s);
+            const uint64_t told = old_total[ci][k];
+            const bool received = s.total != told;
+            if (kf == s.buf.base && !received && s.buf.end == s.total)
+                continue;
+            const bool span0 = (k == 0 && c.has_span);
+            const uint64_t cnt = told > kf ? told - kf : 0;
+            const float *src = nullptr;
+            if (span0 && kf >= c.span.first)
+                src = c.span.d_x + (kf - c.span.first);
+            else if (span0)
+                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
+            else if (cnt)
+                src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
+            if (s.total - kf > s.buf.cap)
+                return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
+            const int other = s.buf.cur ^ 1;
+            if (cnt)
+                tjobs.push_back({src, s.buf.p[other], (int)cnt});
+            s.buf.cur = other;
+            s.buf.base = kf;
+            s.buf.end = s.total;
         }
-        HIPCHK(h, launch_tail(tb, h->stream));
+    }
+    // epilogue launches: fold the partials and carry the tails together
+    for (size_t ri = 0, ti = 0; ri < rjobs.size() || ti < tjobs.size();) {
+        RedBatch rb{};
+        rb.n = (int)h->n;
+        for (; ri < rjobs.size() && rb.njobs < MAX_JOBS; ++ri)
+            rb.jobs[rb.njobs++] = rjobs[ri];
+        TailBatch tb{};
+        for (; ti < tjobs.size() && tb.njobs < MAX_JOBS; ++ti)
+            tb.jobs[tb.njobs++] = tjobs[ti];
+        HIPCHK(h, launch_post(rb, tb, h->stream));
     }
     for (auto &c : h->ch) {
         c.has_span = false;
