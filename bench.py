@@ -50,16 +50,34 @@ def cpu_baseline(n, seconds=12.0):
                       f"reference quotes >200 MS/s/core for N=512 (README.md:11)"}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per dominant launch from the latest committed PMC passes (profiles/*_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE of the same bench command under rocprofv3 --pmc); None if not measured."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel:
+            best = d
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=1024, help="FFT size N")
     ap.add_argument("--log2-batch", type=int, default=26, help="samples per channel per step = 2^this")
     ap.add_argument("--channels-per-gpu", type=int, default=1)
     ap.add_argument("--detrend", default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -72,12 +90,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the PSD path has no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = entry.load_package()
     n, C = args.n, args.channels_per_gpu
@@ -117,14 +140,15 @@ def main():
     ns = bank.num_stages(0)
     spec, meta = shard.pack_readout(bank, C, n, torch)
     if dist is not None:
-        specs, metas = shard.gather_readout(dist, spec, meta, device=torch.device("cuda", local_rank))
+        specs, metas = shard.gather_readout(
+            dist, spec, meta, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     else:
         specs, metas = [spec], [meta]
     merged = shard.stitch_gathered(pkg, n, specs, metas, [C] * world) if rank == 0 else None
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -138,6 +162,8 @@ def main():
         kern_s = prof["kernel_ms"] * 1e-3
         ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
+        kname = "fused1024_kernel" if n == 1024 and args.detrend == "none" else "welch_kernel"
+        tr = measured_traffic(kname) if (C == 1 and args.log2_batch == 26) else None
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,
             "value": msps, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,8 +176,11 @@ def main():
                        "fft_size": n, "channels": C * world, "samples_per_step_per_channel": T,
                        "stages": ns, "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "fused1024_kernel" if n == 1024 and args.detrend == "none" else "welch_kernel", "launches": prof["launches"],
+                         "frac": ach / HBM_PEAK_GBPS,
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_source": (tr["round"] + " PMC passes, profiles/") if tr else None,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * T * C,
+                         "kernel": kname, "launches": prof["launches"],
                          "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
                          "algorithmic_bytes_per_sample": ALG_BYTES_PER_SAMPLE},
             "compute_roofline": {"bound": "fp32_valu", "achieved": flop * msps * 1e6 / 1e12 / world,

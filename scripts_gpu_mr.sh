@@ -1,0 +1,9 @@
+#!/bin/bash
+# rehearsal of the multi-rank bench path on ONE GPU: 2 ranks, gloo, both on cuda:0
+mkdir -p gpurun_out
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 3 --backend gloo --single-device --log2-batch 24 > gpurun_out/bench_mr.log 2>&1
+rc=$?
+echo "rc=$rc"; grep '^{' gpurun_out/bench_mr.log | cut -c1-600 || tail -20 gpurun_out/bench_mr.log
+[ $rc -eq 0 ] || tail -20 gpurun_out/bench_mr.log
+timeout -k 10 300 python bench.py --steps 100 --warmup 5 --cpu-seconds 6 > gpurun_out/bench_default.log 2>&1
+echo "rc=$?"; grep '^{' gpurun_out/bench_default.log
