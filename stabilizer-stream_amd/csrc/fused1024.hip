@@ -105,7 +105,35 @@ __device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const floa
     y1 = e1 + a1;
 }
 
-__global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES_PER_SIMD) void fused1024_kernel(const FusedBatch batch,
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
+{
+    // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
+    const int m = step > job.is_m1 ? step : job.is_m1;
+    const int na = job.nb - m;
+    if (na <= 0)
+        return 1.0f;
+    return (float)exp2(0.5 * (double)na * job.log2_gamma);
+}
+
+// DETREND: 0 None, 1 Midpoint, 2 Span, 3 Mean (src/psd.rs:75-113).  EWMA: per-segment
+// amplitude sqrt(W) so that the two-for-one identity still yields the weighted sum.
+// The Span / Mean / EWMA variants need a few more registers than the 128 that four
+// wavefronts per SIMD allow; they are built for two per SIMD rather than spilling.
+template <int DETREND, bool EWMA>
+__global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSED_WAVES_PER_SIMD) void fused1024_kernel(const FusedBatch batch,
                                                                        const float *__restrict__ win)
 {
     using namespace w1024;
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES_PER_SIMD) void fused1
     // the lower half of chunk p + 2 into `lo`, in flight during the FFT passes.  For pair
     // p + 1 the roles are (lo, up, nl) <- (nl, up, lo).
     auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool more,
-                         float *o) {
+                         float *o, int p) {
         // ---- decimator: inputs rel r = 0..1311 <-> src[1024 p + 224 + r] ----
         if (t >= X_SKIP / 4) {
             const int h = 2 * (t - X_SKIP / 4);
@@ -212,24 +240,78 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES_PER_SIMD) void fused1
         // ---- FFT of the pair: re = segment 2p, im = segment 2p + 1 ----
         cf v[16];
         {
+            // segment a = samples [0, 1024) of (lo, up), segment b = (up, nl).  The trend is removed as
+            // (x - o) - (m + n s): o is a sample of the segment (exact difference), the remainder is small,
+            // so a DC level far above the noise does not cost the result its low bits.
+            float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
+            if constexpr (DETREND == 1) { // Midpoint: x[N/2] (src/psd.rs:87-93)
+                oa = lane_bcast(up[0].x, 0);
+                ob = lane_bcast(nl[0].x, 0);
+            } else if constexpr (DETREND == 2) { // Span (src/psd.rs:94-102), ramp as o + n s
+                oa = lane_bcast(lo[0].x, 0);
+                sa = (lane_bcast(up[1].w, 63) - oa) / 1023.0f;
+                ob = lane_bcast(up[0].x, 0);
+                sb = (lane_bcast(nl[1].w, 63) - ob) / 1023.0f;
+            } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109)
+                // summed about a pivot (the segment's midpoint sample) so that a large DC level
+                // does not cost the f32 sum its low bits: mean = pivot + sum(x - pivot) / N
+                const float pa = lane_bcast(up[0].x, 0), pb = lane_bcast(nl[0].x, 0);
+                auto s4 = [](const float4 &v, float pv) { return ((v.x - pv) + (v.y - pv)) + ((v.z - pv) + (v.w - pv)); };
+                const float sl = s4(lo[0], pa) + s4(lo[1], pa);
+                const float sua = s4(up[0], pa) + s4(up[1], pa);
+                const float sub = s4(up[0], pb) + s4(up[1], pb);
+                const float sn = s4(nl[0], pb) + s4(nl[1], pb);
+                oa = pa;
+                ob = pb;
+                ma = wave_sum(sl + sua) * (1.0f / 1024.0f);
+                mb = wave_sum(sub + sn) * (1.0f / 1024.0f);
+            }
+            float ga = 1.0f, gb = 1.0f;
+            if constexpr (EWMA) {
+                if (job.ewma) {
+                    ga = fused_ewma_amp(job, job.step0 + 2 * p);
+                    gb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                }
+            }
+            const float nf = (float)(4 * t);
+            auto put = [&](int slot, float xa, float xb, float w, int nofs) {
+                if constexpr (DETREND == 1) {
+                    xa -= oa;
+                    xb -= ob;
+                } else if constexpr (DETREND == 2) {
+                    const float n = nf + (float)nofs;
+                    xa = fmaf(-n, sa, xa - oa);
+                    xb = fmaf(-n, sb, xb - ob);
+                } else if constexpr (DETREND == 3) {
+                    xa = (xa - oa) - ma;
+                    xb = (xb - ob) - mb;
+                }
+                xa *= w;
+                xb *= w;
+                if constexpr (EWMA) {
+                    xa *= ga;
+                    xb *= gb;
+                }
+                v[slot] = {xa, xb};
+            };
             const float4 w0 = s_win[t], w1 = s_win[64 + t], w2 = s_win[128 + t], w3 = s_win[192 + t];
             const float4 a0 = lo[0], a1 = lo[1], a2 = up[0], a3 = up[1], b2 = nl[0], b3 = nl[1];
-            v[0] = {a0.x * w0.x, a2.x * w0.x};
-            v[1] = {a0.y * w0.y, a2.y * w0.y};
-            v[2] = {a0.z * w0.z, a2.z * w0.z};
-            v[3] = {a0.w * w0.w, a2.w * w0.w};
-            v[4] = {a1.x * w1.x, a3.x * w1.x};
-            v[5] = {a1.y * w1.y, a3.y * w1.y};
-            v[6] = {a1.z * w1.z, a3.z * w1.z};
-            v[7] = {a1.w * w1.w, a3.w * w1.w};
-            v[8] = {a2.x * w2.x, b2.x * w2.x};
-            v[9] = {a2.y * w2.y, b2.y * w2.y};
-            v[10] = {a2.z * w2.z, b2.z * w2.z};
-            v[11] = {a2.w * w2.w, b2.w * w2.w};
-            v[12] = {a3.x * w3.x, b3.x * w3.x};
-            v[13] = {a3.y * w3.y, b3.y * w3.y};
-            v[14] = {a3.z * w3.z, b3.z * w3.z};
-            v[15] = {a3.w * w3.w, b3.w * w3.w};
+            put(0, a0.x, a2.x, w0.x, 0);
+            put(1, a0.y, a2.y, w0.y, 1);
+            put(2, a0.z, a2.z, w0.z, 2);
+            put(3, a0.w, a2.w, w0.w, 3);
+            put(4, a1.x, a3.x, w1.x, 256);
+            put(5, a1.y, a3.y, w1.y, 257);
+            put(6, a1.z, a3.z, w1.z, 258);
+            put(7, a1.w, a3.w, w1.w, 259);
+            put(8, a2.x, b2.x, w2.x, 512);
+            put(9, a2.y, b2.y, w2.y, 513);
+            put(10, a2.z, b2.z, w2.z, 514);
+            put(11, a2.w, b2.w, w2.w, 515);
+            put(12, a3.x, b3.x, w3.x, 768);
+            put(13, a3.y, b3.y, w3.y, 769);
+            put(14, a3.z, b3.z, w3.z, 770);
+            put(15, a3.w, b3.w, w3.w, 771);
         }
         if (more) { // pair p + 1 exists: chunk p + 1 upper -> up, chunk p + 2 lower -> lo
             up[0] = cnext[128];
@@ -270,11 +352,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, FUSED_WAVES_PER_SIMD) void fused1
         gc[1] = cp[256 + 64];
         float *o = job.dst + (size_t)p0 * 128;
         for (int p = p0; p < p1; p += 2) {
-            pair_step(ga, gb, gc, cp + 256, p + 1 < p1, o);
+            pair_step(ga, gb, gc, cp + 256, p + 1 < p1, o, p);
             cp += 256;
             o += 128;
             if (p + 1 < p1) {
-                pair_step(gc, gb, ga, cp + 256, p + 2 < p1, o);
+                pair_step(gc, gb, ga, cp + 256, p + 2 < p1, o, p + 1);
                 cp += 256;
                 o += 128;
             }
@@ -301,7 +383,23 @@ hipError_t launch_fused1024(const FusedBatch &b, const float *win, hipStream_t s
 {
     if (b.nblocks <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(fused1024_kernel, dim3(b.nblocks), dim3(FUSED_WAVES * 64), 0, s, b, win);
+    const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
+#define PSDK_FUSED_CASE(D)                                                              \
+    case D:                                                                             \
+        if (b.any_ewma)                                                                 \
+            hipLaunchKernelGGL((fused1024_kernel<D, true>), grid, block, 0, s, b, win);  \
+        else                                                                            \
+            hipLaunchKernelGGL((fused1024_kernel<D, false>), grid, block, 0, s, b, win); \
+        break;
+    switch (b.detrend) {
+        PSDK_FUSED_CASE(0)
+        PSDK_FUSED_CASE(1)
+        PSDK_FUSED_CASE(2)
+        PSDK_FUSED_CASE(3)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef PSDK_FUSED_CASE
     return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ struct RedBatch {
     RedJob jobs[MAX_JOBS];
 };
 
-// Fused fast path (N = 1024, Hann, Detrend::None, plain sum): a run of whole
+// Fused fast path (N = 1024, Hann; any implemented detrend; sum or EWMA): a run of whole
 // segment PAIRS.  Pair i = segments (seg_a + 2i, seg_a + 2i + 1) = samples
 // src[1024 i .. 1024 i + 1536); its 1024 new samples src[1024 i + 512 ..) are
 // decimated to 128 outputs dst[128 i ..).  src must be 16-byte aligned.
@@ -77,15 +77,22 @@ struct FusedJob {
     const float *src;   // first sample of segment seg_a
     float *dst;         // where decimator output 64 (seg_a + 1) lands in the next stage's stream
     float *partial;     // [nblocks][1024]
+    double log2_gamma;  // EWMA, as in SegJob
     int npairs;
     int run;            // consecutive pairs per wavefront (workgroup b owns pairs [b, b+1) * waves * run)
     int block_begin;
     int nblocks;
+    int step0;          // EWMA: 1-based batch step of segment seg_a
+    int nb;
+    int is_m1;
+    int ewma;
 };
 
 struct FusedBatch {
     int njobs;
     int nblocks;
+    int detrend;  // Detrend kind 0..3 for every job of the launch
+    int any_ewma; // some job has finite averaging weights
     FusedJob jobs[MAX_JOBS];
 };
 

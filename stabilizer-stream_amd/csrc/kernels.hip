@@ -114,8 +114,9 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 rb[i * P0::R + m] = act_b ? xb[nidx] : 0.0f;
             }
 
-        // Detrend (src/psd.rs:75-113): offset(n) = o0 + n * sl
-        float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f;
+        // Detrend (src/psd.rs:75-113) as (x - o) - (m + n s): o is a sample of the segment, so the
+        // first difference is exact and a DC level far above the noise costs no low bits
+        float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
         if (detrend == 1) { // Midpoint :87-93
             oa = act_a ? xa[N / 2] : 0.0f;
             ob = act_b ? xb[N / 2] : 0.0f;
@@ -128,12 +129,13 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 ob = xb[0];
                 sb = (xb[N - 1] - ob) / (float)(N - 1);
             }
-        } else if (detrend == 3) { // Mean :103-109
+        } else if (detrend == 3) { // Mean :103-109, summed about the midpoint sample (pivot)
+            const float va = act_a ? xa[N / 2] : 0.0f, vb = act_b ? xb[N / 2] : 0.0f;
             float pa = 0.0f, pb = 0.0f;
 #pragma unroll
             for (int s = 0; s < E; ++s) {
-                pa += ra[s];
-                pb += rb[s];
+                pa += ra[s] - va;
+                pb += rb[s] - vb;
             }
             constexpr int W = TEAM < 64 ? TEAM : 64;
 #pragma unroll
@@ -157,8 +159,10 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 }
                 __syncthreads();
             }
-            oa = pa / (float)N;
-            ob = pb / (float)N;
+            oa = va;
+            ob = vb;
+            ma = pa / (float)N;
+            mb = pb / (float)N;
         }
 
         float ampa = 1.0f, ampb = 1.0f;
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 const float w = win[nidx];
                 float a = ra[s], b = rb[s];
                 if (detrend != 0) {
-                    a -= fmaf((float)nidx, sa, oa);
-                    b -= fmaf((float)nidx, sb, ob);
+                    a = fmaf(-(float)nidx, sa, a - oa) - ma;
+                    b = fmaf(-(float)nidx, sb, b - ob) - mb;
                 }
                 a *= w;
                 b *= w;

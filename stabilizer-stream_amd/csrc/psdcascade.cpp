@@ -266,7 +266,7 @@ int advance_round(psdc_handle *h, bool *did_work)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
-    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN && h->detrend == PSDC_DETREND_NONE;
+    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN;
     // the seam must complete every segment that starts in the carried tail; on the fast path
     // one more hop so that the tail side can end on a whole segment pair
     const uint64_t seam = (uint64_t)h->n + std::max<uint64_t>(HBF_HALO, fast_ok ? g.hop : 0);
@@ -311,7 +311,7 @@ int advance_round(psdc_handle *h, bool *did_work)
                     std::min<uint64_t>(j_new, std::max<uint64_t>(w.j_old, (first + g.hop - 1) / g.hop));
                 uint64_t m_split =
                     std::min<uint64_t>(m_new, std::max<uint64_t>(m_old, (first + HBF_HALO + 7) / 8));
-                if (fast_ok && !w.ew.ewma && w.j_old > 0 && ((j_split - w.j_old) & 1) && j_split < j_new &&
+                if (fast_ok && w.j_old > 0 && ((j_split - w.j_old) & 1) && j_split < j_new &&
                     (j_split + 2) * g.hop <= first + seam) {
                     // fast path: give the tail side a whole number of segment pairs and exactly
                     // their decimator outputs, so that neither side leaves work for the generic kernels
@@ -424,7 +424,7 @@ int advance_round(psdc_handle *h, bool *did_work)
         };
         for (int i = 0; i < w.nspans; ++i) {
             const Span &sp = w.spans[i];
-            uint64_t np = (fast_ok && !w.ew.ewma && nx) ? (sp.seg_b - sp.seg_a) / 2 : 0;
+            uint64_t np = (fast_ok && nx) ? (sp.seg_b - sp.seg_a) / 2 : 0;
             const float *fsrc = sp.src + (g.hop * sp.seg_a - sp.src_base);
             const uint64_t mf0 = 64 * (sp.seg_a + 1), mf1 = mf0 + 128 * np;
             if (np && ((reinterpret_cast<uintptr_t>(fsrc) & 15u) != 0 || mf0 < sp.m_a || mf1 > sp.m_b))
@@ -434,6 +434,12 @@ int advance_round(psdc_handle *h, bool *did_work)
                 fj.src = fsrc;
                 fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
                 fj.npairs = (int)np;
+                fj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                                  : -std::numeric_limits<double>::infinity();
+                fj.step0 = (int)(sp.seg_a - w.j_old) + 1;
+                fj.nb = (int)w.ew.nb;
+                fj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+                fj.ewma = w.ew.ewma ? 1 : 0;
                 fjobs.push_back({fj, wi});
                 add_seg(sp, sp.seg_a + 2 * np, sp.seg_b);
                 add_dec(sp, sp.m_a, mf0);
@@ -523,10 +529,12 @@ int advance_round(psdc_handle *h, bool *did_work)
     };
     for (size_t i = 0; i < fjobs.size();) {
         FusedBatch fb{};
+        fb.detrend = h->detrend;
         for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
             FusedJob j = fjobs[i].j;
             j.block_begin = fb.nblocks;
             fb.nblocks += j.nblocks;
+            fb.any_ewma |= j.ewma;
             fb.jobs[fb.njobs++] = j;
         }
         ProfEvents pe{};

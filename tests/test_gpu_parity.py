@@ -127,19 +127,20 @@ def test_chunking_invariance(pkg, ora, gpu_required):
     many.close()
 
 
+@pytest.mark.parametrize("n", [64, 1024])
 @pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (0xFFFFFFFF, 40), (5, 1000), (0, 7), (1, 1)])
-def test_ewma_parity(pkg, ora, gpu_required, limit, count):
-    """Finite averaging (src/psd.rs:218-233, :431-436)."""
-    n = 64
-    x = make_signal(pkg, 60000, seed=11, tone=0.2)
+def test_ewma_parity(pkg, ora, gpu_required, limit, count, n):
+    """Finite averaging (src/psd.rs:218-233, :431-436); n = 1024 runs the fused kernel's EWMA variant."""
+    sc = n // 64
+    x = make_signal(pkg, 60000 * sc, seed=11, tone=0.2)
     avg = pkg.AvgOpts(limit, count)
     g = pkg.PsdCascadeBank(n)
-    g.configure(quantum=7000)
+    g.configure(quantum=7000 * sc)
     g.set_avg(avg)
-    chunks = [x[:20000], x[20000:20011], x[20011:]]
+    chunks = [x[:20000 * sc], x[20000 * sc:20000 * sc + 11], x[20000 * sc + 11:]]
     for c in chunks:
         g.process(0, c)
-    check_against_oracle(pkg, ora, g, chunks, n, avg=avg, what=f"ewma {limit},{count}")
+    check_against_oracle(pkg, ora, g, chunks, n, avg=avg, what=f"ewma {limit},{count} N={n}")
     g.close()
 
 
@@ -271,6 +272,22 @@ def test_device_resident_input(pkg, ora, gpu_required):
     check_against_oracle(pkg, ora, g2, [x], n, what="mixed input")
     g.close()
     g2.close()
+
+
+@pytest.mark.parametrize("detrend", ["midpoint", "span", "mean"])
+def test_device_resident_detrend(pkg, ora, gpu_required, detrend):
+    """Zero-copy spans through the fused kernel's detrend variants (src/psd.rs:75-113)."""
+    import torch
+    n = 1024
+    x = make_signal(pkg, 400000, seed=71, tone=0.3, dc=5.0, f0=0.0003)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    g.process_device(0, xd.data_ptr(), 250000)
+    g.process_device(0, xd.data_ptr() + 4 * 250000, 150000)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, what=f"device {detrend}")
+    g.close()
 
 
 def test_noise_generator_twin(pkg, gpu_required):
