@@ -147,6 +147,18 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
 int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
                                size_t n_frames, size_t *n_ok);
 
+/* Loss (src/loss.rs:3-26): sequence-gap accounting over the frames ingested by
+ * psdc_process_adcdac_frames.  received counts batches; dropped the batches missing
+ * between consecutive frames (u32 wrapping_sub); gaps are counted, never zero-filled. */
+typedef struct psdc_loss {
+    uint64_t received;
+    uint64_t dropped;
+    uint32_t next_seq;  /* seq expected from the next frame */
+    uint32_t have_seq;  /* 0 until the first frame was seen */
+} psdc_loss;
+
+int psdc_loss_read(psdc_handle *h, psdc_loss *out, int reset);
+
 /* Enqueue every complete segment of every stage now (does not wait). */
 int psdc_flush(psdc_handle *h);
 

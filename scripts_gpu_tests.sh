@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
+rc=$?
+echo "pytest rc=$rc"; tail -6 gpurun_out/pytest_gpu.log
+exit $rc

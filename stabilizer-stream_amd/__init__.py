@@ -88,6 +88,11 @@ class _CStageStat(C.Structure):
                 ("pending", C.c_uint64), ("processed", C.c_uint64)]
 
 
+class _CLoss(C.Structure):
+    _fields_ = [("received", C.c_uint64), ("dropped", C.c_uint64),
+                ("next_seq", C.c_uint32), ("have_seq", C.c_uint32)]
+
+
 class _CProfile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("kernel_ms", C.c_double),
                 ("samples", C.c_uint64), ("stage0_samples", C.c_uint64)]
@@ -172,6 +177,7 @@ def lib():
     f("psdc_process", i32, [H, u32, fp, sz])
     f("psdc_process_device", i32, [H, u32, C.c_void_p, sz])
     f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
+    f("psdc_loss_read", i32, [H, C.POINTER(_CLoss), i32])
     f("psdc_flush", i32, [H])
     f("psdc_sync", i32, [H])
     f("psdc_num_stages", i32, [H, u32])
@@ -198,7 +204,7 @@ def lib():
 EXPORTS = [
     "psdc_abi_version", "psdc_last_error", "psdc_create", "psdc_destroy", "psdc_clone", "psdc_reset",
     "psdc_configure", "psdc_set_detrend", "psdc_set_avg", "psdc_process", "psdc_process_device",
-    "psdc_process_adcdac_frames", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
+    "psdc_process_adcdac_frames", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
     "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
@@ -280,6 +286,12 @@ class PsdCascadeBank:
         if rc < 0:
             _raise(rc, self._h)
         return ok.value
+
+    def loss(self, reset=False):
+        """Loss counters (src/loss.rs): batches received / dropped over the ingested frames."""
+        l = _CLoss()
+        self._ck(self._L.psdc_loss_read(self._h, C.byref(l), int(reset)))
+        return {"received": l.received, "dropped": l.dropped}
 
     def flush(self):
         self._ck(self._L.psdc_flush(self._h))

@@ -93,6 +93,7 @@ struct psdc_handle {
     bool profile = false;
     std::vector<ProfEvents> prof_pending;
     psdc_profile prof{};
+    psdc_loss loss{};
     std::string err;
 };
 
@@ -1144,6 +1145,15 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
             break;
         }
     }
+    for (size_t i = 0; i < good; ++i) { // Loss::update (src/loss.rs:11-26)
+        const uint8_t *f = frames + i * frame_size;
+        const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+        h->loss.received += f[3];
+        if (h->loss.have_seq)
+            h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
+        h->loss.next_seq = seq + f[3];                              // wrapping_add
+        h->loss.have_seq = 1;
+    }
     if (good > 0 && batches > 0) {
         // order behind anything pending on these channels
         bool pend = false;
@@ -1205,6 +1215,16 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                     bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
                     : bad == PSDC_ERR_FRAME_FORMAT ? "Unknown or non-AdcDac format ID"
                                                    : "Payload size");
+    return PSDC_OK;
+}
+
+int psdc_loss_read(psdc_handle *h, psdc_loss *out, int reset)
+{
+    if (!h || !out)
+        return fail(h, PSDC_ERR_ARG, "null argument");
+    *out = h->loss;
+    if (reset)
+        h->loss = psdc_loss{};
     return PSDC_OK;
 }
 

@@ -1,0 +1,126 @@
+"""Feed side: the reference's `Source` for its two file formats (src/source.rs), plus the batched
+feeders a GPU path needs.
+
+`Source.get()` keeps the reference contract -- one call returns `[(name, f32 array), ...]`, one entry per
+trace, with the reference's own granularity (`Data::Raw`: at most 2048 bytes = 512 samples per call,
+src/source.rs:150-157; `Data::File`: one frame of `frame_size` bytes per call, :136-142; `--repeat` wraps
+at EOF, :143-145,152-155).  At 10 GS/s that granularity would mean 2e7 calls/s, so `feed()` reads MB-scale
+spans of the SAME byte formats and hands them to `psdc_process` / `psdc_process_adcdac_frames` in bulk:
+the cascade's result depends only on the concatenated stream, so both ways give the same PSD.
+
+UDP, the noise generator and the DSM source are host I/O outside the accelerated path.
+"""
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+
+@dataclass
+class SourceOpts:
+    """File-backed subset of SourceOpts (src/source.rs:15-48)."""
+    file: Optional[str] = None          # frames file (--file)
+    frame_size: int = 8 + 30 * 2 * 6 * 4  # default of the reference CLI (src/source.rs:31)
+    repeat: bool = False                # --repeat
+    raw: Optional[str] = None           # single f32 raw trace, native endian (--raw)
+
+
+class Source:
+    """Source::new / get / finish (src/source.rs:66-171) for Data::File and Data::Raw."""
+
+    RAW_CHUNK = 2048  # bytes per get() (src/source.rs:151)
+
+    def __init__(self, opts: SourceOpts, pkg=None):
+        if (opts.file is None) == (opts.raw is None):
+            raise ValueError("exactly one of file / raw (UDP, noise, dsm sources are out of scope)")
+        self.opts = opts
+        self._f = open(opts.file if opts.file else opts.raw, "rb")
+        self._pkg = pkg
+        self.received = 0  # Loss (src/loss.rs) for the get() path
+        self.dropped = 0
+        self._seq = None
+
+    def close(self):
+        self._f.close()
+
+    # -- reference-granularity path -------------------------------------------------
+    def get(self):
+        """One reference-sized chunk: [(name, np.float32 array)], or raises EOFError at end of file."""
+        if self.opts.raw is not None:
+            while True:
+                buf = self._f.read(self.RAW_CHUNK)
+                if len(buf) == 0:
+                    if self.opts.repeat and os.path.getsize(self.opts.raw) >= 4:
+                        self._f.seek(0)
+                        continue
+                    raise EOFError
+                n = len(buf) // 4 * 4  # bytemuck::cast_slice(&buf[..len / 4 * 4]) (src/source.rs:156)
+                return [("raw", np.frombuffer(buf[:n], dtype="<f4").astype(np.float32))]
+        while True:
+            buf = self._f.read(self.opts.frame_size)
+            if len(buf) < self.opts.frame_size:
+                if self.opts.repeat and os.path.getsize(self.opts.file) >= self.opts.frame_size:
+                    self._f.seek(0)
+                    continue
+                raise EOFError  # read_exact: UnexpectedEof (src/source.rs:137-146)
+            seq, batches, traces = decode_adcdac_frame(buf)
+            self.received += batches  # Loss::update (src/loss.rs:11-26)
+            if self._seq is not None:
+                self.dropped += (seq - self._seq) & 0xFFFFFFFF
+            self._seq = (seq + batches) & 0xFFFFFFFF
+            return traces
+
+    # -- batched path ---------------------------------------------------------------
+    def feed(self, bank, max_bytes=64 << 20, channel=0):
+        """Read up to max_bytes and ingest them in one call.  Returns the bytes consumed (0 at EOF)."""
+        if self.opts.raw is not None:
+            buf = self._f.read(max_bytes // 4 * 4)
+            if len(buf) < 4:
+                if self.opts.repeat and os.path.getsize(self.opts.raw) >= 4 and len(buf) == 0:
+                    self._f.seek(0)
+                    return self.feed(bank, max_bytes, channel)
+                return 0
+            n = len(buf) // 4 * 4
+            bank.process(channel, np.frombuffer(buf[:n], dtype="<f4"))
+            return n
+        fs = self.opts.frame_size
+        buf = self._f.read(max(1, max_bytes // fs) * fs)
+        nframes = len(buf) // fs
+        if nframes == 0:
+            if self.opts.repeat and os.path.getsize(self.opts.file) >= fs:
+                self._f.seek(0)
+                return self.feed(bank, max_bytes, channel)
+            return 0
+        bank.process_adcdac_frames(buf[:nframes * fs], fs)
+        return nframes * fs
+
+    def finish(self):
+        """Loss::analyze (src/loss.rs:28-38): fraction of dropped batches on the get() path."""
+        tot = self.received + self.dropped
+        return (self.dropped / tot) if self.received else 0.0
+
+
+def decode_adcdac_frame(buf):
+    """Frame::from_bytes + AdcDac::traces on the host (src/de/frame.rs:25-60, src/de/data.rs:11-82).
+    Only used by the reference-granularity `get()` path; bulk ingest decodes on the device."""
+    if len(buf) < 8:
+        raise ValueError("frame shorter than its header")
+    if buf[0] != 0x7B or buf[1] != 0x05:
+        raise ValueError("Invalid frame header")
+    if buf[2] != 1:
+        raise ValueError("Unknown format ID" if not 1 <= buf[2] <= 4 else "not an AdcDac frame")
+    batches = buf[3]
+    seq = int.from_bytes(buf[4:8], "little")
+    pay = np.frombuffer(buf[8:], dtype="<i2")
+    if (len(buf) - 8) % 64 or (len(buf) - 8) // 64 != batches:
+        raise ValueError("Payload size")
+    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)  # src/de/data.rs:28-35
+    d = pay.reshape(batches, 4, 8)
+    out = []
+    for c, name in enumerate(("ADC0", "ADC1", "DAC0", "DAC1")):
+        v = d[:, c, :].reshape(-1)
+        if c >= 2:  # i16.wrapping_add(i16::MIN) (src/de/data.rs:64,75)
+            v = (v.astype(np.int32) + 32768 + 32768) % 65536 - 32768
+        out.append((name, v.astype(np.float32) * lsb))
+    return seq, batches, out

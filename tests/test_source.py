@@ -1,0 +1,104 @@
+"""Feed side: the reference's file formats through the Source mirror."""
+import numpy as np
+import pytest
+
+from conftest import test_signal as make_signal
+
+
+def _raw_file(tmp_path, x):
+    p = tmp_path / "trace.f32"
+    x.astype("<f4").tofile(p)  # stream_to_raw.rs:24-25 layout
+    return str(p)
+
+
+def test_raw_get_granularity_and_repeat(pkg, tmp_path):
+    from stabilizer_stream_amd import source
+    x = make_signal(pkg, 1300, seed=1)
+    s = source.Source(source.SourceOpts(raw=_raw_file(tmp_path, x)))
+    got = []
+    sizes = []
+    while True:
+        try:
+            (name, v), = s.get()
+        except EOFError:
+            break
+        assert name == "raw"
+        sizes.append(v.size)
+        got.append(v)
+    assert sizes == [512, 512, 276]  # <= 2048 B per call (src/source.rs:150-157)
+    assert np.array_equal(np.concatenate(got), x)
+    r = source.Source(source.SourceOpts(raw=_raw_file(tmp_path, x), repeat=True))
+    tot = sum(r.get()[0][1].size for _ in range(7))
+    assert tot == 2 * 1300 + 512  # wraps at EOF (src/source.rs:152-155)
+
+
+def test_frame_get_matches_oracle_and_counts_loss(pkg, ora, tmp_path):
+    from stabilizer_stream_amd import source
+    raw = np.random.default_rng(2).integers(-32768, 32768, size=(4, 8 * 3 * 10)).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, 3, seq0=0xFFFFFFF0)
+    frames = [data[i * fs:(i + 1) * fs] for i in range(10)]
+    del frames[4:6]  # lose two frames = 6 batches
+    p = tmp_path / "frames.bin"
+    p.write_bytes(b"".join(frames))
+    s = source.Source(source.SourceOpts(file=str(p), frame_size=fs))
+    n = 0
+    while True:
+        try:
+            traces = s.get()
+        except EOFError:
+            break
+        st, seq, nb, tr = ora.adcdac_decode(frames[n])
+        assert [t[0] for t in traces] == list(pkg.ADCDAC_TRACES)
+        for (name, v), r in zip(traces, tr):
+            assert np.array_equal(v, r)
+        n += 1
+    assert n == 8 and (s.received, s.dropped) == (24, 6)
+    assert s.finish() == pytest.approx(6 / 30)
+    with pytest.raises(ValueError):
+        source.decode_adcdac_frame(b"\x00" * fs)
+
+
+@pytest.mark.gpu
+def test_feeders_on_gpu(pkg, ora, gpu_required, tmp_path):
+    """Bulk feeders give the same PSD as the reference-granularity get() loop, and the frame path
+    reports the reference's Loss counters."""
+    from stabilizer_stream_amd import source
+    from test_gpu_parity import check_against_oracle
+    n = 256
+    x = make_signal(pkg, 200000, seed=3, tone=0.2)
+    path = _raw_file(tmp_path, x)
+    bulk = pkg.PsdCascadeBank(n)
+    s = source.Source(source.SourceOpts(raw=path))
+    while s.feed(bulk, max_bytes=1 << 18):
+        pass
+    check_against_oracle(pkg, ora, bulk, [x], n, what="raw bulk feed")
+    small = pkg.PsdCascadeBank(n)
+    s = source.Source(source.SourceOpts(raw=path))
+    while True:
+        try:
+            small.process(0, s.get()[0][1])
+        except EOFError:
+            break
+    for k in range(bulk.num_stages()):
+        assert bulk.stage_info(0, k) == small.stage_info(0, k)
+        a, b = bulk.stage_spectrum(0, k), small.stage_spectrum(0, k)
+        assert np.allclose(a, b, rtol=2e-6, atol=1e-6 * float(np.mean(a)))
+    # frames with a gap
+    raw = np.random.default_rng(4).integers(-32768, 32768, size=(4, 8 * 22 * 200)).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, 22, seq0=5)
+    frames = [data[i * fs:(i + 1) * fs] for i in range(200)]
+    del frames[50:53]
+    fp = tmp_path / "frames.bin"
+    fp.write_bytes(b"".join(frames))
+    g = pkg.PsdCascadeBank(n, 4)
+    s = source.Source(source.SourceOpts(file=str(fp), frame_size=fs))
+    while s.feed(g, max_bytes=60 * fs):
+        pass
+    assert g.loss() == {"received": 197 * 22, "dropped": 3 * 22}
+    keep = np.r_[0:50, 53:200]
+    for c in range(4):
+        st_all = [ora.adcdac_decode(frames[i])[3][c] for i in range(197)]
+        check_against_oracle(pkg, ora, g, [np.concatenate(st_all)], n, channel=c, what=f"frames ch{c}")
+    bulk.close()
+    small.close()
+    g.close()
