@@ -50,6 +50,25 @@ def cpu_baseline(n, seconds=12.0):
                       f"reference quotes >200 MS/s/core for N=512 (README.md:11)"}
 
 
+def host_fed_rate(pkg, n, device, seconds=2.0):
+    """PCIe-inclusive ingest: psdc_process() on host memory (copy into pinned staging, H2D, kernels).
+    Reported beside the headline, never as `value`."""
+    x = pkg.noise_host(1 << 24, 0x7654321)
+    bank = pkg.PsdCascadeBank(n, 1, device=device)
+    bank.process(0, x)
+    bank.sync()
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < seconds:
+        bank.process(0, x)
+        done += x.size
+    bank.sync()
+    dt = time.perf_counter() - t0
+    bank.close()
+    return {"value": done / dt / 1e6, "unit": "MS/s",
+            "note": "host numpy buffer -> psdc_process (memcpy to pinned staging + hipMemcpyAsync + kernels), 1 host thread"}
+
+
 def measured_traffic(kernel):
     """HBM bytes per dominant launch from the latest committed PMC passes (profiles/*_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE of the same bench command under rocprofv3 --pmc); None if not measured."""
@@ -189,6 +208,7 @@ def main():
                                  "algorithmic_flop_per_sample": flop},
         }
         if world == 1 and not args.no_cpu_baseline:
+            out["host_fed"] = host_fed_rate(pkg, n, local_rank)
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out))
     bank.close()
