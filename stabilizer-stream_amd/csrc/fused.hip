@@ -1,0 +1,510 @@
+// fused.hip -- the hot kernel for N = 256, 512, 1024 (Hann): detrend + window +
+// two-for-one FFT + |Z|^2 accumulate (src/psd.rs:211-233) AND the /8 half-band
+// decimation of the same samples (src/psd.rs:246-253) in one pass over the stream.
+//
+// A TEAM of N/16 lanes (1, 2 or 4 teams per wavefront) owns a run of consecutive
+// segment pairs.  Pair p = segments (2p, 2p+1) of the job = samples
+// src[N p .. N p + 3N/2); its N new samples src[N p + N/2 ..) are decimated to N/8
+// outputs.  Per pair the team
+//   - holds chunk p and the lower half of chunk p + 1 in registers (four dwordx4 per
+//     lane per chunk, straight from HBM; the next ones are in flight during the FFT),
+//   - runs the three half-band stages out of its private LDS frame: polyphase even/odd
+//     arrays, two outputs per lane per step so that LDS accesses are aligned 8-byte
+//     ones; the filter state (the last 22 stage-A and 58 stage-B outputs) is carried
+//     from pair to pair in a small LDS side buffer, so nothing is recomputed,
+//   - runs the (4, N/64, 16) team FFT of fft_team.h through the same frame,
+//   - adds |Z|^2 into 16 registers per lane.
+// LDS operations of one wavefront execute in order, so inside a run only compiler-level
+// ordering is needed: there is no workgroup barrier in the loop.
+#include "fft_team.h"
+#include "hbf_taps.h"
+#include "kernels.h"
+
+namespace psdk {
+
+template <int N>
+struct FusedGeo {
+    using T = TeamFft<N>;
+    static constexpr int TEAM = T::TEAM, TPW = T::TPW;
+    static constexpr int TEAMS = FUSED_WAVES * TPW;      // teams per workgroup
+    static constexpr int SCR = 2 * T::FRAME;             // floats of a team's frame
+    // decimator arrays inside the frame: [history | new], even/odd polyphase, even sizes
+    static constexpr int HX = 12, HA = 22, HB = 58;      // carried samples per stage input
+    static constexpr int XE = 0, XO = XE + HX / 2 + N / 2;
+    static constexpr int AE = XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
+    static constexpr int BE = AO + 12 + N / 4, BO = BE + 30 + N / 8;
+    static constexpr int END = BO + 30 + N / 8;
+    static_assert(END <= SCR, "decimator arrays exceed the frame");
+    static constexpr int HIST = HA + HB;                 // floats of carried state per team
+    // warm-up (stateless block ending at the first new sample of a run)
+    static constexpr int WX = HBF_HALO, WA = HBF_PRE_A, WB = HBF_PRE_B; // 288, 138, 58
+    static constexpr int WXE = 0, WXO = WX / 2, WAE = WX, WAO = WX + WA / 2 + 1;
+    static_assert(WAO + WA / 2 + 1 <= SCR, "warm-up arrays exceed the frame");
+    // polyphase offsets, the same in both forms (history sizes chosen for that)
+    static constexpr int A_CE = 4, A_CO = 1, B_CE = 6, B_CO = 0, C_CE = 15, C_CO = 0;
+    static_assert(HX / 2 - 2 == A_CE && HX / 2 - 5 == A_CO, "x history vs stage A offsets");
+    static_assert(HA / 2 - 5 == B_CE && HA / 2 - 11 == B_CO, "A history vs stage B offsets");
+    static_assert(HB / 2 - 14 == C_CE && HB / 2 - 29 == C_CO, "B history vs stage C offsets");
+    static_assert(WX / 2 - WA - HBF_MA + 1 == A_CE && WA / 2 - WB - HBF_MB + 1 == B_CE, "warm-up geometry");
+    static constexpr size_t LDS_BYTES = sizeof(cf) * (TEAMS * T::FRAME + T::TW0_SIZE + T::TW1_SIZE) +
+                                        sizeof(float) * (N + TEAMS * HIST);
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wavefront execute in order; this only stops the
+    // compiler from moving LDS accesses across the hand-off between lanes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
+
+// two consecutive outputs (j, j+1), j even, of a half-band stage with M unique taps:
+// out j = ev[j + CE] + sum_i taps[i] (od[j + CO + i] + od[j + CO + 2M-1-i]); odd array read
+// as aligned pairs.
+template <int M, int CE, int CO>
+__device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const float *__restrict__ od, int j,
+                                        const float (&taps)[M], float &y0, float &y1)
+{
+    constexpr int LO = CO & ~1;                // aligned start
+    constexpr int CNT = (CO - LO) + 2 * M + 1; // values needed from od[j + LO]
+    constexpr int NP = (CNT + 1) / 2;
+    float w[2 * NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const f2 v = ld2(od + j + LO + 2 * k);
+        w[2 * k] = v.x;
+        w[2 * k + 1] = v.y;
+    }
+    constexpr int O = CO - LO;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        a0 += (w[O + i] + w[O + 2 * M - 1 - i]) * taps[i];
+        a1 += (w[O + 1 + i] + w[O + 2 * M - i]) * taps[i];
+    }
+    float e0, e1;
+    if constexpr ((CE & 1) == 0) {
+        const f2 e = ld2(ev + j + CE);
+        e0 = e.x;
+        e1 = e.y;
+    } else {
+        e0 = ev[j + CE];
+        e1 = ev[j + CE + 1];
+    }
+    y0 = e0 + a0;
+    y1 = e1 + a1;
+}
+
+template <int TEAM>
+__device__ __forceinline__ float team_bcast(float v, int team_lane0, int tl)
+{
+    return __shfl(v, team_lane0 + tl, 64);
+}
+
+template <int TEAM>
+__device__ __forceinline__ float team_sum(float v)
+{
+#pragma unroll
+    for (int o = TEAM / 2; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
+{
+    // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
+    const int m = step > job.is_m1 ? step : job.is_m1;
+    const int na = job.nb - m;
+    if (na <= 0)
+        return 1.0f;
+    return (float)exp2(0.5 * (double)na * job.log2_gamma);
+}
+
+// DETREND: 0 None, 1 Midpoint, 2 Span, 3 Mean (src/psd.rs:75-113).  EWMA: per-segment
+// amplitude sqrt(W) so that the two-for-one identity still yields the weighted sum.
+// The Span / Mean / EWMA variants need a few more registers than the 128 that four
+// wavefronts per SIMD allow; they are built for two per SIMD rather than spilling.
+template <int N, int DETREND, bool EWMA>
+__global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSED_WAVES_PER_SIMD) void fused_kernel(
+    const FusedBatch batch, const float *__restrict__ win)
+{
+    using G = FusedGeo<N>;
+    using T = TeamFft<N>;
+    constexpr int TEAM = G::TEAM, TPW = G::TPW, TEAMS = G::TEAMS;
+    __shared__ cf s_frames[TEAMS * T::FRAME];
+    __shared__ cf s_tw0[T::TW0_SIZE];
+    __shared__ cf s_tw1[T::TW1_SIZE > 0 ? T::TW1_SIZE : 1];
+    __shared__ float4 s_win[N / 4]; // window: float4 piece m of team-lane tl at [TEAM m + tl]
+    __shared__ float s_hist[TEAMS * G::HIST];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int tm = lane / TEAM, tl = lane % TEAM; // team within the wavefront, lane within the team
+    const int team = wv * TPW + tm;               // team within the workgroup
+
+    for (int i = tid; i < T::TW0_SIZE; i += FUSED_WAVES * 64) { // [c][tl]: W_N^(4 tl + c)
+        const int c = i / TEAM, l = i % TEAM;
+        float sn, cs;
+        sincospif(-2.0f * (float)(4 * l + c) / (float)N, &sn, &cs);
+        s_tw0[i] = {cs, sn};
+    }
+    for (int i = tid; i < T::TW1_SIZE; i += FUSED_WAVES * 64) { // [(q-1)][s]: W_L1^(s q)
+        const int q = i / 16 + 1, s = i % 16;
+        float sn, cs;
+        sincospif(-2.0f * (float)(s * q) / (float)T::L1, &sn, &cs);
+        s_tw1[i] = {cs, sn};
+    }
+    for (int i = tid; i < N / 4; i += FUSED_WAVES * 64)
+        s_win[i] = *reinterpret_cast<const float4 *>(win + 4 * i); // (src/psd.rs:44-48 table)
+
+    int ji = 0;
+    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
+        ++ji;
+    const FusedJob &job = batch.jobs[ji];
+    const int wb = blockIdx.x - job.block_begin;
+    const int npairs = job.npairs, run = job.run;
+
+    cf *frame = s_frames + team * T::FRAME;
+    float *sf = reinterpret_cast<float *>(frame);
+    float *hs = s_hist + team * G::HIST; // [0,11) AE, [11,22) AO, [22,51) BE, [51,80) BO
+
+    const float ta[HBF_MA] = {PSDK_HBF_TAPS_A};
+    const float tb[HBF_MB] = {PSDK_HBF_TAPS_B};
+    const float tc[HBF_MC] = {PSDK_HBF_TAPS_C};
+
+    // where the carried filter state sits in the frame: tail (after a pair) and front (before one)
+    // (packed: tail << 16 | front, 0xFFFF = none, to keep the register count at 128)
+    constexpr int HR = (G::HIST + TEAM - 1) / TEAM;
+    unsigned h_pack[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        const int i = tl + TEAM * r;
+        int front = -1, shift = 0;
+        if (i < 11) {
+            front = G::AE + i;
+            shift = N / 4;
+        } else if (i < 22) {
+            front = G::AO + (i - 11);
+            shift = N / 4;
+        } else if (i < 51) {
+            front = G::BE + (i - 22);
+            shift = N / 8;
+        } else if (i < 80) {
+            front = G::BO + (i - 51);
+            shift = N / 8;
+        }
+        h_pack[r] = front < 0 ? 0xFFFFu : ((unsigned)(front + shift) << 16) | (unsigned)front;
+    }
+
+    float q[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        q[s] = 0.0f;
+
+    __syncthreads(); // tables ready
+
+    // this team's run: pairs [p0, p0 + run) of the job (possibly cut by npairs)
+    const int p0 = (wb * TEAMS + team) * run;
+    const bool act0 = p0 < npairs;
+    const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tl;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ga[2] = {z4, z4}, gb[2] = {z4, z4}, gc[2] = {z4, z4};
+    if (act0) { // chunk p0 (all of it exists) and the lower half of chunk p0 + 1
+        ga[0] = cp[0];
+        ga[1] = cp[TEAM];
+        gb[0] = cp[2 * TEAM];
+        gb[1] = cp[3 * TEAM];
+        gc[0] = cp[N / 4];
+        gc[1] = cp[N / 4 + TEAM];
+    }
+
+    // ---- warm-up: filter state at the first new sample of the run ------------------------
+    // Evaluate stages A and B on the 288 samples before it (zeros before the start of the
+    // stream, which is the reference's zero initial state, src/psd.rs:141) and keep their tails.
+    {
+        const float *xn = job.src + (size_t)p0 * N + N / 2; // first new sample of the run
+        const long long lim = -(long long)job.pre - ((long long)p0 * N + N / 2); // xn[i] valid for i >= lim
+        for (int r = tl; r < G::WX / 2; r += TEAM) {
+            const int i0 = 2 * r - G::WX;
+            float e = 0.0f, o = 0.0f;
+            if (act0 && i0 >= lim) {
+                e = xn[i0];
+                o = xn[i0 + 1];
+            }
+            sf[G::WXE + r] = e;
+            sf[G::WXO + r] = o;
+        }
+        wave_sync();
+        for (int u = tl; u < G::WA / 2; u += TEAM) {
+            float y0, y1;
+            hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::WXE, sf + G::WXO, 2 * u, ta, y0, y1);
+            sf[G::WAE + u] = y0;
+            sf[G::WAO + u] = y1;
+            if (u >= G::WA / 2 - 11) {
+                hs[u - (G::WA / 2 - 11)] = y0;
+                hs[11 + u - (G::WA / 2 - 11)] = y1;
+            }
+        }
+        wave_sync();
+        for (int u = tl; u < G::WB / 2; u += TEAM) {
+            float y0, y1;
+            hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::WAE, sf + G::WAO, 2 * u, tb, y0, y1);
+            hs[22 + u] = y0;
+            hs[51 + u] = y1;
+        }
+        wave_sync();
+    }
+
+    // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
+    // nl = lower half of chunk p + 1.  Once lo/up have been windowed into the FFT registers
+    // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
+    // chunk p + 2 into `lo`, in flight during the FFT passes.  For pair p + 1 the roles are
+    // (lo, up, nl) <- (nl, up, lo).
+    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool act,
+                         bool more, float *o, int p) {
+        // ---- decimator ------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
+            if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
+                sf[h_pack[r] & 0xFFFFu] = hs[tl + TEAM * r];
+        if (tl >= TEAM - 3) { // the 12 samples before the new ones (end of chunk p's lower half)
+            const int h = 2 * (tl - (TEAM - 3));
+            *reinterpret_cast<f2 *>(sf + G::XE + h) = {lo[1].x, lo[1].z};
+            *reinterpret_cast<f2 *>(sf + G::XO + h) = {lo[1].y, lo[1].w};
+        }
+        {
+            const int h = G::HX / 2 + 2 * tl;
+            *reinterpret_cast<f2 *>(sf + G::XE + h) = {up[0].x, up[0].z};
+            *reinterpret_cast<f2 *>(sf + G::XO + h) = {up[0].y, up[0].w};
+            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 8) = {up[1].x, up[1].z};
+            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 8) = {up[1].y, up[1].w};
+            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 4) = {nl[0].x, nl[0].z};
+            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 4) = {nl[0].y, nl[0].w};
+            *reinterpret_cast<f2 *>(sf + G::XE + h + 3 * N / 8) = {nl[1].x, nl[1].z};
+            *reinterpret_cast<f2 *>(sf + G::XO + h + 3 * N / 8) = {nl[1].y, nl[1].w};
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, (2u, 2u+1) -> AE/AO[11 + u]
+            const int u = tl + TEAM * r;
+            float y0, y1;
+            hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
+            sf[G::AE + 11 + u] = y0;
+            sf[G::AO + 11 + u] = y1;
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { // stage B: N/4 outputs -> BE/BO[29 + u]
+            const int u = tl + TEAM * r;
+            float y0, y1;
+            hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 2 * u, tb, y0, y1);
+            sf[G::BE + 29 + u] = y0;
+            sf[G::BO + 29 + u] = y1;
+        }
+        wave_sync();
+        { // stage C: N/8 outputs, two per lane, straight to the next stage's stream
+            float y0, y1;
+            hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tl, tc, y0, y1);
+            if (act) {
+                o[2 * tl] = y0;
+                o[2 * tl + 1] = y1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < HR; ++r) // tails of A and B -> carried state
+            if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
+                hs[tl + TEAM * r] = sf[h_pack[r] >> 16];
+        wave_sync(); // the frame is reused by the FFT
+
+        // ---- FFT of the pair: re = segment 2p, im = segment 2p + 1 -------------------------
+        cf v[16];
+        {
+            // segment a = (lo, up), segment b = (up, nl).  The trend is removed as
+            // (x - o) - (m + n s): o is a sample of the segment (exact difference), the remainder is
+            // small, so a DC level far above the noise does not cost the result its low bits.
+            float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
+            const int l0 = lane - tl; // first lane of this team
+            if constexpr (DETREND == 1) { // Midpoint: x[N/2] (src/psd.rs:87-93)
+                oa = team_bcast<TEAM>(up[0].x, l0, 0);
+                ob = team_bcast<TEAM>(nl[0].x, l0, 0);
+            } else if constexpr (DETREND == 2) { // Span (src/psd.rs:94-102), ramp as o + n s
+                oa = team_bcast<TEAM>(lo[0].x, l0, 0);
+                sa = (team_bcast<TEAM>(up[1].w, l0, TEAM - 1) - oa) / (float)(N - 1);
+                ob = team_bcast<TEAM>(up[0].x, l0, 0);
+                sb = (team_bcast<TEAM>(nl[1].w, l0, TEAM - 1) - ob) / (float)(N - 1);
+            } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109), summed about the midpoint sample
+                oa = team_bcast<TEAM>(up[0].x, l0, 0);
+                ob = team_bcast<TEAM>(nl[0].x, l0, 0);
+                auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
+                const float sl = s4(lo[0], oa) + s4(lo[1], oa);
+                const float sua = s4(up[0], oa) + s4(up[1], oa);
+                const float sub = s4(up[0], ob) + s4(up[1], ob);
+                const float sn = s4(nl[0], ob) + s4(nl[1], ob);
+                ma = team_sum<TEAM>(sl + sua) * (1.0f / (float)N);
+                mb = team_sum<TEAM>(sub + sn) * (1.0f / (float)N);
+            }
+            float ea = 1.0f, eb = 1.0f;
+            if constexpr (EWMA) {
+                if (job.ewma) {
+                    ea = fused_ewma_amp(job, job.step0 + 2 * p);
+                    eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                }
+            }
+            const float nf = (float)(4 * tl);
+            auto put = [&](int slot, float xa, float xb, float w, int nofs) {
+                if constexpr (DETREND == 1) {
+                    xa -= oa;
+                    xb -= ob;
+                } else if constexpr (DETREND == 2) {
+                    const float n = nf + (float)nofs;
+                    xa = fmaf(-n, sa, xa - oa);
+                    xb = fmaf(-n, sb, xb - ob);
+                } else if constexpr (DETREND == 3) {
+                    xa = (xa - oa) - ma;
+                    xb = (xb - ob) - mb;
+                }
+                xa *= w;
+                xb *= w;
+                if constexpr (EWMA) {
+                    xa *= ea;
+                    xb *= eb;
+                }
+                v[slot] = {xa, xb};
+            };
+            const float4 w0 = s_win[tl], w1 = s_win[TEAM + tl], w2 = s_win[2 * TEAM + tl], w3 = s_win[3 * TEAM + tl];
+            const float4 a0 = lo[0], a1 = lo[1], a2 = up[0], a3 = up[1], b2 = nl[0], b3 = nl[1];
+            put(0, a0.x, a2.x, w0.x, 0);
+            put(1, a0.y, a2.y, w0.y, 1);
+            put(2, a0.z, a2.z, w0.z, 2);
+            put(3, a0.w, a2.w, w0.w, 3);
+            put(4, a1.x, a3.x, w1.x, N / 4);
+            put(5, a1.y, a3.y, w1.y, N / 4 + 1);
+            put(6, a1.z, a3.z, w1.z, N / 4 + 2);
+            put(7, a1.w, a3.w, w1.w, N / 4 + 3);
+            put(8, a2.x, b2.x, w2.x, N / 2);
+            put(9, a2.y, b2.y, w2.y, N / 2 + 1);
+            put(10, a2.z, b2.z, w2.z, N / 2 + 2);
+            put(11, a2.w, b2.w, w2.w, N / 2 + 3);
+            put(12, a3.x, b3.x, w3.x, 3 * N / 4);
+            put(13, a3.y, b3.y, w3.y, 3 * N / 4 + 1);
+            put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
+            put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
+        }
+        if (more) { // pair p + 1 exists for this team: chunk p + 1 upper -> up, chunk p + 2 lower -> lo
+            up[0] = cnext[2 * TEAM];
+            up[1] = cnext[3 * TEAM];
+            lo[0] = cnext[N / 4];
+            lo[1] = cnext[N / 4 + TEAM];
+        } else {
+            up[0] = up[1] = lo[0] = lo[1] = z4;
+        }
+        T::pass0(tl, v, s_tw0);
+        T::store0(tl, v, frame);
+        wave_sync();
+        T::load1(tl, v, frame);
+        T::pass1(tl, v, s_tw1);
+        wave_sync();
+        T::store1(tl, v, frame);
+        wave_sync();
+        T::load2(tl, v, frame);
+        T::pass2(v);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+        wave_sync(); // next pair's decimator writes the frame
+    };
+
+    {
+        float *o = job.dst + (size_t)p0 * (N / 8);
+        for (int i = 0; i < run; i += 2) {
+            const int p = p0 + i;
+            pair_step(ga, gb, gc, cp + N / 4, p < npairs, (i + 1 < run) && (p + 1 < npairs), o, p);
+            cp += N / 4;
+            o += N / 8;
+            if (i + 1 < run) {
+                pair_step(gc, gb, ga, cp + N / 4, p + 1 < npairs, (i + 2 < run) && (p + 2 < npairs), o, p + 1);
+                cp += N / 4;
+                o += N / 8;
+            }
+        }
+    }
+
+    // combine the teams; partial in natural bin order
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        sf[T::freq_of(tl, s)] = q[s];
+    __syncthreads();
+    const float *all = reinterpret_cast<const float *>(s_frames);
+    float *out = job.partial + (size_t)wb * N;
+    for (int k = tid; k < N; k += FUSED_WAVES * 64) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < TEAMS; ++g)
+            acc += all[g * G::SCR + k];
+        out[k] = acc;
+    }
+}
+
+bool fused_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+
+int fused_pairs_per_block(int n, int run)
+{
+    switch (n) {
+    case 256:
+        return FusedGeo<256>::TEAMS * run;
+    case 512:
+        return FusedGeo<512>::TEAMS * run;
+    case 1024:
+        return FusedGeo<1024>::TEAMS * run;
+    default:
+        return 0;
+    }
+}
+
+template <int N>
+static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s)
+{
+    static_assert(FusedGeo<N>::LDS_BYTES <= 81920, "two workgroups per CU need <= 80 KiB of LDS each");
+    const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
+#define PSDK_FUSED_CASE(D)                                                                \
+    case D:                                                                               \
+        if (b.any_ewma)                                                                   \
+            hipLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, b, win);     \
+        else                                                                              \
+            hipLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, b, win);    \
+        break;
+    switch (b.detrend) {
+        PSDK_FUSED_CASE(0)
+        PSDK_FUSED_CASE(1)
+        PSDK_FUSED_CASE(2)
+        PSDK_FUSED_CASE(3)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef PSDK_FUSED_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, hipStream_t s)
+{
+    if (b.nblocks <= 0)
+        return hipSuccess;
+    switch (n) {
+    case 256:
+        return launch_fused_n<256>(b, win, s);
+    case 512:
+        return launch_fused_n<512>(b, win, s);
+    case 1024:
+        return launch_fused_n<1024>(b, win, s);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+} // namespace psdk

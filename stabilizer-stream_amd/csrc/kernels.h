@@ -69,17 +69,20 @@ struct RedBatch {
     RedJob jobs[MAX_JOBS];
 };
 
-// Fused fast path (N = 1024, Hann; any implemented detrend; sum or EWMA): a run of whole
-// segment PAIRS.  Pair i = segments (seg_a + 2i, seg_a + 2i + 1) = samples
-// src[1024 i .. 1024 i + 1536); its 1024 new samples src[1024 i + 512 ..) are
-// decimated to 128 outputs dst[128 i ..).  src must be 16-byte aligned.
+// Fused fast path (N = 256, 512, 1024, Hann; any implemented detrend; sum or EWMA): a run
+// of whole segment PAIRS.  Pair i = segments (seg_a + 2i, seg_a + 2i + 1) = samples
+// src[N i .. N i + 3N/2); its N new samples src[N i + N/2 ..) are decimated to N/8 outputs
+// dst[(N/8) i ..).  src must be 16-byte aligned.  The decimator state at the start of a run
+// is rebuilt from the 288 samples before its first new sample: `pre` says how many samples in
+// front of src are real memory; anything earlier is the zero history of a fresh stream.
 struct FusedJob {
     const float *src;   // first sample of segment seg_a
     float *dst;         // where decimator output 64 (seg_a + 1) lands in the next stage's stream
-    float *partial;     // [nblocks][1024]
+    float *partial;     // [nblocks][N]
     double log2_gamma;  // EWMA, as in SegJob
     int npairs;
-    int run;            // consecutive pairs per wavefront (workgroup b owns pairs [b, b+1) * waves * run)
+    int run;            // consecutive pairs per team (workgroup b owns pairs [b, b+1) * teams * run)
+    int pre;            // readable samples in front of src
     int block_begin;
     int nblocks;
     int step0;          // EWMA: 1-based batch step of segment seg_a
@@ -104,7 +107,7 @@ struct FusedBatch {
 #endif
 constexpr int FUSED_WAVES = PSDK_FUSED_WAVES;        // wavefronts per workgroup
 constexpr int FUSED_WAVES_PER_SIMD = PSDK_FUSED_WPS; // launch bound: wavefronts per SIMD
-constexpr int FUSED_MAX_BLOCKS = 512;   // 2 workgroups per CU (2 x 81792 B of LDS, 127 VGPRs)
+constexpr int FUSED_MAX_BLOCKS = 512;   // 2 workgroups per CU (<= 80 KiB of LDS each, <= 128 VGPRs)
 
 // Carry the unconsumed tail of a stream to the front of its other buffer.
 struct TailJob {
@@ -125,7 +128,9 @@ constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 
 bool welch_supported(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
-hipError_t launch_fused1024(const FusedBatch &b, const float *win, hipStream_t s);
+bool fused_supported(int n);                 // N = 256, 512, 1024
+int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, hipStream_t s);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);

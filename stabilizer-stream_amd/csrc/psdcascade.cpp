@@ -267,10 +267,14 @@ int advance_round(psdc_handle *h, bool *did_work)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
-    const bool fast_ok = h->n == 1024 && h->window_kind == PSDC_WINDOW_HANN;
-    // the seam must complete every segment that starts in the carried tail; on the fast path
-    // one more hop so that the tail side can end on a whole segment pair
-    const uint64_t seam = (uint64_t)h->n + std::max<uint64_t>(HBF_HALO, fast_ok ? g.hop : 0);
+    const bool fast_ok = fused_supported((int)h->n) && h->window_kind == PSDC_WINDOW_HANN;
+    // fused runs rebuild their decimator state from the 288 samples before their first new
+    // sample (which sits hop after the run's first segment start): samples needed in front of it
+    const uint64_t need_pre = HBF_HALO > g.hop ? HBF_HALO - g.hop : 0;
+    // the seam must complete every segment that starts in the carried tail; on the fast path it
+    // is long enough for the tail side to end on a whole segment pair with need_pre samples of
+    // the new span in front of the in-place side
+    const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * (uint64_t)g.hop : 0);
     *did_work = false;
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
@@ -312,12 +316,16 @@ int advance_round(psdc_handle *h, bool *did_work)
                     std::min<uint64_t>(j_new, std::max<uint64_t>(w.j_old, (first + g.hop - 1) / g.hop));
                 uint64_t m_split =
                     std::min<uint64_t>(m_new, std::max<uint64_t>(m_old, (first + HBF_HALO + 7) / 8));
-                if (fast_ok && w.j_old > 0 && ((j_split - w.j_old) & 1) && j_split < j_new &&
-                    (j_split + 2) * g.hop <= first + seam) {
-                    // fast path: give the tail side a whole number of segment pairs and exactly
-                    // their decimator outputs, so that neither side leaves work for the generic kernels
-                    j_split += 1;
-                    m_split = std::min<uint64_t>(m_new, (j_split + 1) * (g.hop / 8));
+                if (fast_ok && w.j_old > 0) {
+                    // fast path: the tail side gets a whole number of segment pairs and exactly their
+                    // decimator outputs; the in-place side starts >= need_pre samples into the span
+                    uint64_t js = std::max<uint64_t>(w.j_old, (first + need_pre + g.hop - 1) / g.hop);
+                    if ((js - w.j_old) & 1)
+                        js += 1;
+                    if (js < j_new && (js + 1) * g.hop <= first + seam && c.span.len >= seam) {
+                        j_split = js;
+                        m_split = std::min<uint64_t>(m_new, (js + 1) * (g.hop / 8));
+                    }
                 }
                 if (j_split > w.j_old || m_split > m_old)
                     w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_split, m_old, m_split};
@@ -425,24 +433,32 @@ int advance_round(psdc_handle *h, bool *did_work)
         };
         for (int i = 0; i < w.nspans; ++i) {
             const Span &sp = w.spans[i];
-            uint64_t np = (fast_ok && nx) ? (sp.seg_b - sp.seg_a) / 2 : 0;
-            const float *fsrc = sp.src + (g.hop * sp.seg_a - sp.src_base);
-            const uint64_t mf0 = 64 * (sp.seg_a + 1), mf1 = mf0 + 128 * np;
-            if (np && ((reinterpret_cast<uintptr_t>(fsrc) & 15u) != 0 || mf0 < sp.m_a || mf1 > sp.m_b))
+            // first fused segment: far enough into the stream that every output survives the drain
+            uint64_t fs = sp.seg_a;
+            while ((g.hop / 8) * (fs + 1) < g.drain)
+                fs += 2;
+            uint64_t np = (fast_ok && nx && fs + 2 <= sp.seg_b) ? (sp.seg_b - fs) / 2 : 0;
+            const uint64_t fofs = (uint64_t)g.hop * fs - sp.src_base; // samples of this span in front of the pairs
+            const float *fsrc = sp.src + fofs;
+            const uint64_t mf0 = (g.hop / 8) * (fs + 1), mf1 = mf0 + (h->n / 8) * np;
+            if (np && ((reinterpret_cast<uintptr_t>(fsrc) & 15u) != 0 || mf0 < sp.m_a || mf1 > sp.m_b ||
+                       (fofs < need_pre && sp.src_base != 0)))
                 np = 0;
             if (np) {
                 FusedJob fj{};
                 fj.src = fsrc;
                 fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
                 fj.npairs = (int)np;
+                fj.pre = (int)std::min<uint64_t>(fofs, HBF_HALO);
                 fj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
                                                   : -std::numeric_limits<double>::infinity();
-                fj.step0 = (int)(sp.seg_a - w.j_old) + 1;
+                fj.step0 = (int)(fs - w.j_old) + 1;
                 fj.nb = (int)w.ew.nb;
                 fj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
                 fj.ewma = w.ew.ewma ? 1 : 0;
                 fjobs.push_back({fj, wi});
-                add_seg(sp, sp.seg_a + 2 * np, sp.seg_b);
+                add_seg(sp, sp.seg_a, fs);
+                add_seg(sp, fs + 2 * np, sp.seg_b);
                 add_dec(sp, sp.m_a, mf0);
                 add_dec(sp, mf1, sp.m_b);
             } else {
@@ -472,9 +488,10 @@ int advance_round(psdc_handle *h, bool *did_work)
         // workgroups in proportion to the pairs; every wavefront of a job gets the same run
         const uint64_t np = (uint64_t)f.j.npairs;
         const uint64_t share = std::max<uint64_t>(1, (np * FUSED_MAX_BLOCKS + fused_pairs / 2) / fused_pairs);
-        const uint64_t run = (np + share * FUSED_WAVES - 1) / (share * FUSED_WAVES);
+        const uint64_t teams = (uint64_t)fused_pairs_per_block((int)h->n, 1);
+        const uint64_t run = (np + share * teams - 1) / (share * teams);
         f.j.run = (int)run;
-        f.j.nblocks = (int)((np + run * FUSED_WAVES - 1) / (run * FUSED_WAVES));
+        f.j.nblocks = (int)((np + run * teams - 1) / (run * teams));
         blocks_total += (size_t)f.j.nblocks;
     }
     int rc = ensure_partial(h, blocks_total * h->n);
@@ -542,7 +559,7 @@ int advance_round(psdc_handle *h, bool *did_work)
         const bool first = (i <= (size_t)MAX_JOBS);
         if ((rc = prof_begin(pe)))
             return rc;
-        HIPCHK(h, launch_fused1024(fb, h->d_win, h->stream));
+        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->stream));
         if ((rc = prof_end(pe, first)))
             return rc;
     }

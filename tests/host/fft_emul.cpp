@@ -4,7 +4,7 @@
 // (ds_read_b64: two 32-lane groups, 64 banks x 4 B; ds_write_b64: four
 // 16-lane groups, 32 banks x 4 B).  Build: g++ -O2 -std=c++17 -I<csrc>.
 #include "fft_core.h"
-#include "fft_wave1024.h"
+#include "fft_team.h"
 #include <cmath>
 #include <algorithm>
 #include <complex>
@@ -135,67 +135,45 @@ static int check(bool rotate)
     return (seen == N && err < 2e-6) ? 0 : 1;
 }
 
-// the wave-level (4,16,16) FFT of the fused kernel
-static int check_wave1024()
+// team FFT of the fused kernel: numerics per team and LDS conflicts of a whole wavefront
+// (TPW teams side by side, frames contiguous)
+template <int N>
+static int check_team()
 {
-    using namespace w1024;
-    std::vector<cf> z(N), frame(FRAME), tw0(TW0_SIZE), tw1(TW1_SIZE);
-    srand(99);
+    using T = TeamFft<N>;
+    constexpr int TEAM = T::TEAM, TPW = T::TPW, FR = T::FRAME;
+    std::vector<cf> z(N), frame(FR), tw0(T::TW0_SIZE), tw1(T::TW1_SIZE > 0 ? T::TW1_SIZE : 1);
+    srand(7 + N);
     for (int i = 0; i < N; ++i) {
         z[i].re = (float)rand() / RAND_MAX - 0.5f;
         z[i].im = (float)rand() / RAND_MAX - 0.5f;
     }
-    for (int q = 1; q < 4; ++q)
-        for (int s = 0; s < 256; ++s) {
-            double a = -2.0 * M_PI * (double)(s * q) / 1024.0;
-            tw0[(q - 1) * 256 + s] = {(float)cos(a), (float)sin(a)};
+    for (int c = 0; c < 4; ++c)
+        for (int tl = 0; tl < TEAM; ++tl) {
+            double a = -2.0 * M_PI * (double)(4 * tl + c) / (double)N;
+            tw0[c * TEAM + tl] = {(float)cos(a), (float)sin(a)};
         }
-    for (int q = 1; q < 16; ++q)
+    for (int q = 1; q < T::R1; ++q)
         for (int s = 0; s < 16; ++s) {
-            double a = -2.0 * M_PI * (double)(s * q) / 256.0;
+            double a = -2.0 * M_PI * (double)(s * q) / (double)T::L1;
             tw1[(q - 1) * 16 + s] = {(float)cos(a), (float)sin(a)};
         }
-    std::vector<std::vector<cf>> regs(64, std::vector<cf>(16));
-    for (int t = 0; t < 64; ++t)
+    std::vector<std::vector<cf>> regs(TEAM, std::vector<cf>(16));
+    for (int t = 0; t < TEAM; ++t)
         for (int m = 0; m < 4; ++m)
             for (int c = 0; c < 4; ++c)
-                regs[t][4 * m + c] = z[4 * t + c + 256 * m];
-    for (int t = 0; t < 64; ++t) pass0(t, regs[t].data(), tw0.data());
-    for (int t = 0; t < 64; ++t) store0(t, regs[t].data(), frame.data());
-    for (int t = 0; t < 64; ++t) load1(t, regs[t].data(), frame.data());
-    for (int t = 0; t < 64; ++t) pass1(t, regs[t].data(), tw1.data());
-    for (int t = 0; t < 64; ++t) store1(t, regs[t].data(), frame.data());
-    for (int t = 0; t < 64; ++t) load2(t, regs[t].data(), frame.data());
-    for (int t = 0; t < 64; ++t) pass2(regs[t].data());
-    // conflicts
-    long rd = 0, rdi = 0, wr = 0, wri = 0;
-    for (int q = 0; q < 4; ++q)
-        for (int c = 0; c < 4; ++c)
-            for (int g = 0; g < 4; ++g) {
-                std::vector<int> sl;
-                for (int t = 16 * g; t < 16 * g + 16; ++t) sl.push_back(swz(256 * q + 4 * t + c));
-                wr += group_cycles(sl, 16), ++wri;
-            }
-    for (int m = 0; m < 16; ++m) {
-        for (int g = 0; g < 2; ++g) {
-            std::vector<int> a, b;
-            for (int t = 32 * g; t < 32 * g + 32; ++t) {
-                a.push_back(swz(256 * (t >> 4) + (t & 15) + 16 * m));
-                b.push_back(swz(16 * t + m));
-            }
-            rd += group_cycles(a, 32) + group_cycles(b, 32), rdi += 2;
-        }
-        for (int g = 0; g < 4; ++g) {
-            std::vector<int> a;
-            for (int t = 16 * g; t < 16 * g + 16; ++t) a.push_back(swz(256 * (t >> 4) + (t & 15) + 16 * m));
-            wr += group_cycles(a, 16), ++wri;
-        }
-    }
+                regs[t][4 * m + c] = z[4 * t + c + (N / 4) * m];
+    for (int t = 0; t < TEAM; ++t) T::pass0(t, regs[t].data(), tw0.data());
+    for (int t = 0; t < TEAM; ++t) T::store0(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::load1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::pass1(t, regs[t].data(), tw1.data());
+    for (int t = 0; t < TEAM; ++t) T::store1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::load2(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::pass2(regs[t].data());
     std::vector<std::complex<double>> w(N);
     for (int i = 0; i < N; ++i) w[i] = std::polar(1.0, -2.0 * M_PI * i / N);
-    std::vector<double> got(N, -1.0);
+    std::vector<double> got(N, -1.0), pw(N);
     double err = 0, pmax = 0;
-    std::vector<double> pw(N);
     for (int k = 0; k < N; ++k) {
         std::complex<double> acc = 0;
         for (int j = 0; j < N; ++j)
@@ -203,19 +181,47 @@ static int check_wave1024()
         pw[k] = std::norm(acc);
         pmax = std::max(pmax, pw[k]);
     }
-    for (int t = 0; t < 64; ++t)
+    for (int t = 0; t < TEAM; ++t)
         for (int q = 0; q < 16; ++q) {
-            int k = freq_of(t, q);
+            int k = T::freq_of(t, q);
             if (k < 0 || k >= N || got[k] >= 0) {
-                printf("wave1024: bad/duplicate k=%d\n", k);
+                printf("team<%d>: bad/duplicate k=%d\n", N, k);
                 return 1;
             }
             got[k] = (double)regs[t][q].re * regs[t][q].re + (double)regs[t][q].im * regs[t][q].im;
         }
     for (int k = 0; k < N; ++k) err = std::max(err, fabs(got[k] - pw[k]) / pmax);
-    printf("wave1024 (4,16,16): max|dP|/Pmax=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
-           err, rd, rdi, wr, wri);
-    return (err < 2e-6 && rd == rdi && wr == wri) ? 0 : 1;
+    // conflicts over a wavefront: lane l -> team l / TEAM at frame offset team * FR
+    auto phys = [&](int l, int idx) { return (l / TEAM) * FR + idx; };
+    long rd = 0, rdi = 0, wr = 0, wri = 0;
+    auto rd_instr = [&](auto addr) {
+        for (int g = 0; g < 2; ++g) {
+            std::vector<int> sl;
+            for (int l = 32 * g; l < 32 * g + 32; ++l) sl.push_back(addr(l));
+            rd += group_cycles(sl, 32), ++rdi;
+        }
+    };
+    auto wr_instr = [&](auto addr) {
+        for (int g = 0; g < 4; ++g) {
+            std::vector<int> sl;
+            for (int l = 16 * g; l < 16 * g + 16; ++l) sl.push_back(addr(l));
+            wr += group_cycles(sl, 16), ++wri;
+        }
+    };
+    for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 4; ++c)
+            wr_instr([&](int l) { int tl = l % TEAM; return phys(l, 4 * tl + (tl >> 2) + (T::L1 + T::L1 / 16) * q + c); });
+    for (int i = 0; i < T::NB1; ++i)
+        for (int m = 0; m < T::R1; ++m) {
+            auto a = [&](int l) { int tl = l % TEAM; return phys(l, T::base1(tl) + T::STEP1 * i + 17 * m); };
+            rd_instr(a);
+            wr_instr(a);
+        }
+    for (int m = 0; m < 16; ++m)
+        rd_instr([&](int l) { int tl = l % TEAM; return phys(l, 17 * tl + m); });
+    printf("team<%4d> (4,%2d,16) x%d per wave: max|dP|/Pmax=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
+           N, T::R1, TPW, err, rd, rdi, wr, wri);
+    return (err < 2e-6) ? 0 : 1;
 }
 
 int main()
@@ -233,7 +239,9 @@ int main()
     bad |= check<4096>(false);
     bad |= check<8192>(false);
     bad |= check<16384>(false);
-    bad |= check_wave1024();
+    bad |= check_team<256>();
+    bad |= check_team<512>();
+    bad |= check_team<1024>();
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }
