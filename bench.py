@@ -144,8 +144,11 @@ def main():
         bank.sync()
         torch.cuda.synchronize()
 
+    from stabilizer_stream_amd import shard
     for _ in range(args.warmup):
         step()
+    if args.warmup:
+        shard.pack_readout(bank, C, n, torch)  # first-use costs of the read-out path belong to the warm-up
     barrier()
     bank.configure(profile=True)
     bank.profile_read(reset=True)
@@ -153,9 +156,11 @@ def main():
     for _ in range(args.steps):
         step()
     host_enqueue_s = time.perf_counter() - t0  # host time to enqueue all steps (GPU still running)
+    if os.environ.get("PSD_BENCH_DEBUG"):
+        bank.sync()
+        t_sync = time.perf_counter() - t0
     # read-out: every rank's raw per-stage accumulators + counters to rank 0 in ONE RCCL gather,
     # then the host stitch (PsdCascade::psd) per channel on rank 0
-    from stabilizer_stream_amd import shard
     ns = bank.num_stages(0)
     spec, meta = shard.pack_readout(bank, C, n, torch)
     if dist is not None:
@@ -164,8 +169,13 @@ def main():
     else:
         specs, metas = [spec], [meta]
     merged = shard.stitch_gathered(pkg, n, specs, metas, [C] * world) if rank == 0 else None
+    if os.environ.get("PSD_BENCH_DEBUG"):
+        t_read = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("PSD_BENCH_DEBUG"):
+        print(f"[debug] enqueue {host_enqueue_s*1e3:.2f} ms, +sync {t_sync*1e3:.2f} ms, +readout {t_read*1e3:.2f} ms, "
+              f"total {dt*1e3:.2f} ms", file=sys.stderr)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -183,6 +183,13 @@ int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out
 int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out, size_t cap,
                    size_t *len);
 
+/* Bulk read-out of one channel: stage count, per-stage records and the raw accumulators of
+ * every stage (stage 0 first, n/2+1 floats each) with one flush, one sync and one copy.
+ * stats / spectra may be NULL; cap = stages the caller has room for.  What a multi-GPU
+ * gather or a GUI refresh (src/bin/psd.rs:201) needs per trace. */
+int psdc_read_channel(psdc_handle *h, uint32_t channel, uint32_t cap, uint32_t *n_stages,
+                      psdc_stage_stat *stats, float *spectra);
+
 /* PsdCascade::psd(&MergeOpts) (src/psd.rs:479-543).  psd_out needs room for
  * num_stages*(n/2+1) floats, breaks for num_stages records (lowest rate first).
  * Either output pointer may be NULL to query sizes only. */

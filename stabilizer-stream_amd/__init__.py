@@ -185,6 +185,7 @@ def lib():
     f("psdc_stage_spectrum", i32, [H, u32, u32, fp])
     f("psdc_stage_gain", i32, [H, u32, u32, fp])
     f("psdc_stage_buf", i32, [H, u32, u32, fp, sz, C.POINTER(sz)])
+    f("psdc_read_channel", i32, [H, u32, u32, C.POINTER(u32), C.POINTER(_CStageStat), fp])
     f("psdc_psd", i32, [H, u32, i32, u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz,
                         C.POINTER(sz)])
     f("psdc_rbw", C.c_float, [H])
@@ -205,7 +206,7 @@ EXPORTS = [
     "psdc_abi_version", "psdc_last_error", "psdc_create", "psdc_destroy", "psdc_clone", "psdc_reset",
     "psdc_configure", "psdc_set_detrend", "psdc_set_avg", "psdc_process", "psdc_process_device",
     "psdc_process_adcdac_frames", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
-    "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_psd", "psdc_rbw",
+    "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_read_channel", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
 ]
@@ -323,6 +324,17 @@ class PsdCascadeBank:
         out = np.empty(ln.value, dtype=np.float32)
         self._ck(self._L.psdc_stage_buf(self._h, channel, stage, _fptr(out), out.size, C.byref(ln)))
         return out
+
+    def read_channel(self, channel=0):
+        """All stages of one channel in one call: ([{count, avg, pending, processed}], spectra[ns, n/2+1])."""
+        ns = C.c_uint32()
+        self._ck(self._L.psdc_read_channel(self._h, channel, 0, C.byref(ns), None, None))
+        st = (_CStageStat * max(1, ns.value))()
+        sp = np.empty((ns.value, self.n // 2 + 1), dtype=np.float32)
+        self._ck(self._L.psdc_read_channel(self._h, channel, ns.value, C.byref(ns), st, _fptr(sp) if ns.value else None))
+        info = [{"count": st[k].count, "avg": st[k].avg, "pending": st[k].pending, "processed": st[k].processed}
+                for k in range(ns.value)]
+        return info, sp
 
     def psd(self, channel=0, opts=MergeOpts()):
         ns = self.num_stages(channel)

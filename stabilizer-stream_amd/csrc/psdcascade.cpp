@@ -27,6 +27,8 @@ using namespace psdk;
 
 namespace {
 
+constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the spectra slab
+
 thread_local std::string g_last_error;
 
 struct DevBuf {
@@ -83,6 +85,8 @@ struct psdc_handle {
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
+    float *d_spectra = nullptr; // [n_channels][MAX_STAGES][n] accumulators, one slab
+    bool idle = true;           // nothing ingested since the pipeline was last drained
     float *d_partial = nullptr;
     size_t partial_cap = 0; // floats
     uint8_t *d_frames = nullptr;
@@ -161,17 +165,17 @@ int free_stage(psdc_handle *h, StageState &s)
             HIPCHK(h, hipFree(s.buf.p[i]));
             s.buf.p[i] = nullptr;
         }
-    if (s.spectrum) {
-        HIPCHK(h, hipFree(s.spectrum));
-        s.spectrum = nullptr;
-    }
+    s.spectrum = nullptr; // a slot of the handle's slab
     return PSDC_OK;
 }
 
 int add_stage(psdc_handle *h, Channel &c)
 {
+    if (c.st.size() >= MAX_STAGES)
+        return fail(h, PSDC_ERR_ARG, "more than 16 cascade stages");
     StageState s;
-    HIPCHK(h, hipMalloc(&s.spectrum, sizeof(float) * h->n));
+    const size_t ci = (size_t)(&c - h->ch.data());
+    s.spectrum = h->d_spectra + (ci * MAX_STAGES + c.st.size()) * h->n;
     HIPCHK(h, hipMemsetAsync(s.spectrum, 0, sizeof(float) * h->n, h->stream));
     c.st.push_back(s);
     return PSDC_OK;
@@ -278,18 +282,29 @@ int advance_round(psdc_handle *h, bool *did_work)
     *did_work = false;
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
-    // the carried tail) behind the tail; the bulk is read in place
-    for (auto &c : h->ch) {
-        if (!c.has_span)
-            continue;
-        StageState &s0 = c.st[0];
-        const uint64_t cp = std::min<uint64_t>(seam, c.span.len);
-        int rc = ensure_room(h, s0, c.span.first + cp);
-        if (rc)
-            return rc;
-        HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (c.span.first - s0.buf.base), c.span.d_x,
-                                 sizeof(float) * cp, hipMemcpyDeviceToDevice, h->stream));
-        s0.buf.end = c.span.first + cp;
+    // the carried tail) behind the tail; the bulk is read in place.  One copy
+    // launch for all channels.
+    {
+        std::vector<TailJob> seams;
+        for (auto &c : h->ch) {
+            if (!c.has_span)
+                continue;
+            StageState &s0 = c.st[0];
+            const uint64_t cp = std::min<uint64_t>(seam, c.span.len);
+            int rc = ensure_room(h, s0, c.span.first + cp);
+            if (rc)
+                return rc;
+            seams.push_back({c.span.d_x, s0.buf.p[s0.buf.cur] + (c.span.first - s0.buf.base), (int)cp});
+            s0.buf.end = c.span.first + cp;
+        }
+        for (size_t i = 0; i < seams.size();) {
+            RedBatch none{};
+            none.n = (int)h->n;
+            TailBatch tb{};
+            for (; i < seams.size() && tb.njobs < MAX_JOBS; ++i)
+                tb.jobs[tb.njobs++] = seams[i];
+            HIPCHK(h, launch_post(none, tb, h->stream));
+        }
     }
 
     // collect the work of this round from the totals as they stand now
@@ -472,27 +487,35 @@ int advance_round(psdc_handle *h, bool *did_work)
     }
 
     // share the persistent workgroups so that every workgroup walks about the same amount
-    size_t seg_tiles = 0;
-    for (auto &s : sjobs)
-        seg_tiles += (size_t)s.j.ntiles;
-    uint64_t fused_pairs = 0;
-    for (auto &f : fjobs)
-        fused_pairs += (uint64_t)f.j.npairs;
-    const size_t seg_per = std::max<size_t>(1, (seg_tiles + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS);
+    // shares are computed per launch batch (MAX_JOBS jobs): every launch fills the GPU by itself
     size_t blocks_total = 0;
-    for (auto &s : sjobs) {
-        s.j.nblocks = (int)(((size_t)s.j.ntiles + seg_per - 1) / seg_per);
-        blocks_total += (size_t)s.j.nblocks;
+    for (size_t b0 = 0; b0 < sjobs.size(); b0 += MAX_JOBS) {
+        const size_t b1 = std::min(sjobs.size(), b0 + (size_t)MAX_JOBS);
+        size_t tiles = 0;
+        for (size_t i = b0; i < b1; ++i)
+            tiles += (size_t)sjobs[i].j.ntiles;
+        const size_t per = std::max<size_t>(1, (tiles + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS);
+        for (size_t i = b0; i < b1; ++i) {
+            sjobs[i].j.nblocks = (int)(((size_t)sjobs[i].j.ntiles + per - 1) / per);
+            blocks_total += (size_t)sjobs[i].j.nblocks;
+        }
     }
-    for (auto &f : fjobs) {
-        // workgroups in proportion to the pairs; every wavefront of a job gets the same run
-        const uint64_t np = (uint64_t)f.j.npairs;
-        const uint64_t share = std::max<uint64_t>(1, (np * FUSED_MAX_BLOCKS + fused_pairs / 2) / fused_pairs);
-        const uint64_t teams = (uint64_t)fused_pairs_per_block((int)h->n, 1);
-        const uint64_t run = (np + share * teams - 1) / (share * teams);
-        f.j.run = (int)run;
-        f.j.nblocks = (int)((np + run * teams - 1) / (run * teams));
-        blocks_total += (size_t)f.j.nblocks;
+    const uint64_t teams = (uint64_t)std::max(1, fused_pairs_per_block((int)h->n, 1));
+    for (size_t b0 = 0; b0 < fjobs.size(); b0 += MAX_JOBS) {
+        const size_t b1 = std::min(fjobs.size(), b0 + (size_t)MAX_JOBS);
+        uint64_t pairs = 0;
+        for (size_t i = b0; i < b1; ++i)
+            pairs += (uint64_t)fjobs[i].j.npairs;
+        for (size_t i = b0; i < b1; ++i) {
+            // workgroups in proportion to the pairs; every team of a job gets the same run
+            FusedJob &j = fjobs[i].j;
+            const uint64_t np = (uint64_t)j.npairs;
+            const uint64_t share = std::max<uint64_t>(1, (np * FUSED_MAX_BLOCKS + pairs / 2) / pairs);
+            const uint64_t run = (np + share * teams - 1) / (share * teams);
+            j.run = (int)run;
+            j.nblocks = (int)((np + run * teams - 1) / (run * teams));
+            blocks_total += (size_t)j.nblocks;
+        }
     }
     int rc = ensure_partial(h, blocks_total * h->n);
     if (rc)
@@ -669,13 +692,17 @@ int advance(psdc_handle *h)
 // rounds until the pipeline is idle (read-out path)
 int drain(psdc_handle *h)
 {
+    if (h->idle)
+        return PSDC_OK;
     for (int guard = 0; guard < 64; ++guard) {
         bool did = false;
         int rc = advance_round(h, &did);
         if (rc)
             return rc;
-        if (!did)
+        if (!did) {
+            h->idle = true;
             return PSDC_OK;
+        }
     }
     return fail(h, PSDC_ERR_DEVICE, "internal: pipeline did not drain");
 }
@@ -684,6 +711,7 @@ int submit_host(psdc_handle *h, Channel &c)
 {
     if (c.fill == 0)
         return PSDC_OK;
+    h->idle = false;
     if (c.st.empty()) {
         int rc = add_stage(h, c);
         if (rc)
@@ -916,6 +944,8 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
         return dev_fail(e, "hipMalloc(win)");
     if ((e = hipMalloc(&h->d_tw, sizeof(cf) * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(tw)");
+    if ((e = hipMalloc(&h->d_spectra, sizeof(float) * (size_t)n_channels * MAX_STAGES * n)) != hipSuccess)
+        return dev_fail(e, "hipMalloc(spectra)");
     if ((e = hipMemcpy(h->d_win, win.data(), sizeof(float) * n, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(win)");
     if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
@@ -938,6 +968,8 @@ void psdc_destroy(psdc_handle *h)
     }
     if (h->d_partial)
         (void)hipFree(h->d_partial);
+    if (h->d_spectra)
+        (void)hipFree(h->d_spectra);
     if (h->d_frames)
         (void)hipFree(h->d_frames);
     if (h->h_frames)
@@ -1051,6 +1083,7 @@ int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
         if (rc)
             return rc;
     }
+    h->idle = false;
     while (len > 0) {
         const size_t take = std::min(len, h->quantum - c.fill);
         memcpy(c.stage_host[c.cur_stage] + c.fill, x, sizeof(float) * take);
@@ -1100,6 +1133,7 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
             return rc;
     }
     StageState &s0 = c.st[0];
+    h->idle = false;
     if (len < (size_t)4 * (h->n + HBF_HALO)) {
         // short span: append a copy, like host-fed samples
         rc = ensure_room(h, s0, s0.total + len);
@@ -1214,6 +1248,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                 return rc;
             dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
         }
+        h->idle = false;
         HIPCHK(h, launch_adcdac(h->d_frames, frame_size, good, batches, dst[0], dst[1], dst[2], dst[3],
                                 h->stream));
         for (int ci = 0; ci < 4; ++ci) {
@@ -1355,6 +1390,40 @@ int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out,
     return PSDC_OK;
 }
 
+int psdc_read_channel(psdc_handle *h, uint32_t channel, uint32_t cap, uint32_t *n_stages,
+                      psdc_stage_stat *stats, float *spectra)
+{
+    int rc = check_channel(h, channel);
+    if (rc)
+        return rc;
+    rc = spectra ? flush_sync(h) : flush_all(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[channel];
+    const uint32_t ns = (uint32_t)c.st.size();
+    if (n_stages)
+        *n_stages = ns;
+    if ((stats || spectra) && cap < ns)
+        return fail(h, PSDC_ERR_CAPACITY, "psdc_read_channel: output too small");
+    if (stats)
+        for (uint32_t k = 0; k < ns; ++k) {
+            const StageState &s = c.st[k];
+            stats[k].count = s.count;
+            stats[k].avg = cur_stage_avg(h, k);
+            stats[k].pending = pending_for(h->geo, s.total);
+            const uint32_t cm1 = s.count ? s.count - 1 : 0;
+            stats[k].processed = (uint64_t)h->n * s.count - (uint64_t)h->geo.overlap * cm1;
+        }
+    if (spectra && ns) { // the channel's accumulators are consecutive rows of one slab: one copy
+        std::vector<float> rows((size_t)ns * h->n);
+        HIPCHK(h, hipMemcpy(rows.data(), c.st[0].spectrum, sizeof(float) * rows.size(), hipMemcpyDeviceToHost));
+        const size_t bins = h->n / 2 + 1;
+        for (uint32_t k = 0; k < ns; ++k)
+            memcpy(spectra + k * bins, rows.data() + (size_t)k * h->n, sizeof(float) * bins);
+    }
+    return PSDC_OK;
+}
+
 int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_count,
              int keep_transition_band, float *psd_out, size_t psd_cap, size_t *psd_len,
              psdc_break *breaks, size_t breaks_cap, size_t *n_breaks)
@@ -1375,9 +1444,12 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
         counts[i] = c.st[i].count;
         avgs[i] = cur_stage_avg(h, i);
         pend[i] = pending_for(h->geo, c.st[i].total);
-        if (psd_out)
-            HIPCHK(h, hipMemcpy(spectra.data() + i * bins, c.st[i].spectrum, sizeof(float) * bins,
-                                hipMemcpyDeviceToHost));
+    }
+    if (psd_out && ns) {
+        std::vector<float> rows(ns * h->n);
+        HIPCHK(h, hipMemcpy(rows.data(), c.st[0].spectrum, sizeof(float) * rows.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ns; ++i)
+            memcpy(spectra.data() + i * bins, rows.data() + i * h->n, sizeof(float) * bins);
     }
     rc = stitch_impl(h->n, h->nenbw, h->power, h->geo.overlap, (uint32_t)ns, counts.data(), avgs.data(),
                      pend.data(), spectra.data(), keep_overlap, min_count, keep_transition_band, psd_out,

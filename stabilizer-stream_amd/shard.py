@@ -24,11 +24,15 @@ def pack_readout(bank, n_local, n, torch):
     spec = torch.zeros(n_local, KMAX, bins, dtype=torch.float32)
     meta = torch.zeros(n_local, KMAX, 4, dtype=torch.int64)
     for c in range(n_local):
-        ns = bank.num_stages(c)
-        assert ns <= KMAX
-        for k in range(ns):
-            info = bank.stage_info(c, k)
-            spec[c, k] = torch.from_numpy(np.ascontiguousarray(bank.stage_spectrum(c, k), dtype=np.float32))
+        if hasattr(bank, "read_channel"):  # one flush + one copy per channel
+            infos, sp = bank.read_channel(c)
+        else:
+            infos = [bank.stage_info(c, k) for k in range(bank.num_stages(c))]
+            sp = np.stack([bank.stage_spectrum(c, k) for k in range(len(infos))]) if infos else np.zeros((0, bins))
+        assert len(infos) <= KMAX
+        if len(infos):
+            spec[c, :len(infos)] = torch.from_numpy(np.ascontiguousarray(sp, dtype=np.float32))
+        for k, info in enumerate(infos):
             meta[c, k, 0], meta[c, k, 1], meta[c, k, 2], meta[c, k, 3] = info["count"], info["avg"], info["pending"], 1
     return spec, meta
 

@@ -215,6 +215,24 @@ def test_edges(pkg, ora, gpu_required):
     g.close()
 
 
+def test_bulk_readout(pkg, ora, gpu_required):
+    """psdc_read_channel returns what the per-stage accessors return, in one call."""
+    n = 256
+    g = pkg.PsdCascadeBank(n, 3)
+    infos, sp = g.read_channel(1)
+    assert infos == [] and sp.shape == (0, n // 2 + 1)
+    xs = [make_signal(pkg, 30000 + 7000 * c, seed=80 + c) for c in range(3)]
+    for c in range(3):
+        g.process(c, xs[c])
+    for c in range(3):
+        infos, sp = g.read_channel(c)
+        assert len(infos) == g.num_stages(c)
+        for k, info in enumerate(infos):
+            assert info == g.stage_info(c, k)
+            assert np.array_equal(sp[k], g.stage_spectrum(c, k))
+    g.close()
+
+
 def test_clone_and_reset(pkg, ora, gpu_required):
     n = 64
     x = make_signal(pkg, 30000, seed=51)
