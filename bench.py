@@ -191,7 +191,7 @@ def main():
         kern_s = prof["kernel_ms"] * 1e-3
         ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
-        kname = "fused1024_kernel" if n == 1024 and args.detrend == "none" else "welch_kernel"
+        kname = "fused_kernel" if n in (256, 512, 1024) else "welch_kernel"
         tr = measured_traffic(kname) if (C == 1 and args.log2_batch == 26) else None
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,
