@@ -1,0 +1,11 @@
+// bigfused_2048.hip -- instantiates the workgroup-level fused kernel for N = 2048 (see bigfused_impl.h)
+#include "bigfused_impl.h"
+
+namespace psdk {
+
+hipError_t launch_bigfused_2048(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
+{
+    return launch_bigfused_n<2048>(b, win, tw0g, twag, s);
+}
+
+} // namespace psdk

@@ -1,0 +1,11 @@
+// bigfused_8192.hip -- instantiates the workgroup-level fused kernel for N = 8192 (see bigfused_impl.h)
+#include "bigfused_impl.h"
+
+namespace psdk {
+
+hipError_t launch_bigfused_8192(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
+{
+    return launch_bigfused_n<8192>(b, win, tw0g, twag, s);
+}
+
+} // namespace psdk

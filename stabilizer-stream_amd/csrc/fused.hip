@@ -16,90 +16,25 @@
 //   - adds |Z|^2 into 16 registers per lane.
 // LDS operations of one wavefront execute in order, so inside a run only compiler-level
 // ordering is needed: there is no workgroup barrier in the loop.
+#include <cmath>
+#include <vector>
+
+#include "fft_block.h"
 #include "fft_team.h"
-#include "hbf_taps.h"
-#include "kernels.h"
+#include "fused_common.h"
 
 namespace psdk {
 
 template <int N>
-struct FusedGeo {
+struct FusedGeo : FusedDec<N> {
     using T = TeamFft<N>;
     static constexpr int TEAM = T::TEAM, TPW = T::TPW;
-    static constexpr int TEAMS = FUSED_WAVES * TPW;      // teams per workgroup
-    static constexpr int SCR = 2 * T::FRAME;             // floats of a team's frame
-    // decimator arrays inside the frame: [history | new], even/odd polyphase, even sizes
-    static constexpr int HX = 12, HA = 22, HB = 58;      // carried samples per stage input
-    static constexpr int XE = 0, XO = XE + HX / 2 + N / 2;
-    static constexpr int AE = XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
-    static constexpr int BE = AO + 12 + N / 4, BO = BE + 30 + N / 8;
-    static constexpr int END = BO + 30 + N / 8;
-    static_assert(END <= SCR, "decimator arrays exceed the frame");
-    static constexpr int HIST = HA + HB;                 // floats of carried state per team
-    // warm-up (stateless block ending at the first new sample of a run)
-    static constexpr int WX = HBF_HALO, WA = HBF_PRE_A, WB = HBF_PRE_B; // 288, 138, 58
-    static constexpr int WXE = 0, WXO = WX / 2, WAE = WX, WAO = WX + WA / 2 + 1;
-    static_assert(WAO + WA / 2 + 1 <= SCR, "warm-up arrays exceed the frame");
-    // polyphase offsets, the same in both forms (history sizes chosen for that)
-    static constexpr int A_CE = 4, A_CO = 1, B_CE = 6, B_CO = 0, C_CE = 15, C_CO = 0;
-    static_assert(HX / 2 - 2 == A_CE && HX / 2 - 5 == A_CO, "x history vs stage A offsets");
-    static_assert(HA / 2 - 5 == B_CE && HA / 2 - 11 == B_CO, "A history vs stage B offsets");
-    static_assert(HB / 2 - 14 == C_CE && HB / 2 - 29 == C_CO, "B history vs stage C offsets");
-    static_assert(WX / 2 - WA - HBF_MA + 1 == A_CE && WA / 2 - WB - HBF_MB + 1 == B_CE, "warm-up geometry");
+    static constexpr int TEAMS = FUSED_WAVES * TPW; // teams per workgroup
+    static constexpr int SCR = 2 * T::FRAME;        // floats of a team's frame
+    static_assert(FusedDec<N>::END <= SCR && FusedDec<N>::WEND <= SCR, "decimator arrays exceed the frame");
     static constexpr size_t LDS_BYTES = sizeof(cf) * (TEAMS * T::FRAME + T::TW0_SIZE + T::TW1_SIZE) +
-                                        sizeof(float) * (N + TEAMS * HIST);
+                                        sizeof(float) * (N + TEAMS * FusedDec<N>::HIST);
 };
-
-__device__ __forceinline__ void wave_sync()
-{
-    // LDS operations of one wavefront execute in order; this only stops the
-    // compiler from moving LDS accesses across the hand-off between lanes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct f2 {
-    float x, y;
-};
-__device__ __forceinline__ f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
-
-// two consecutive outputs (j, j+1), j even, of a half-band stage with M unique taps:
-// out j = ev[j + CE] + sum_i taps[i] (od[j + CO + i] + od[j + CO + 2M-1-i]); odd array read
-// as aligned pairs.
-template <int M, int CE, int CO>
-__device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const float *__restrict__ od, int j,
-                                        const float (&taps)[M], float &y0, float &y1)
-{
-    constexpr int LO = CO & ~1;                // aligned start
-    constexpr int CNT = (CO - LO) + 2 * M + 1; // values needed from od[j + LO]
-    constexpr int NP = (CNT + 1) / 2;
-    float w[2 * NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const f2 v = ld2(od + j + LO + 2 * k);
-        w[2 * k] = v.x;
-        w[2 * k + 1] = v.y;
-    }
-    constexpr int O = CO - LO;
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        a0 += (w[O + i] + w[O + 2 * M - 1 - i]) * taps[i];
-        a1 += (w[O + 1 + i] + w[O + 2 * M - i]) * taps[i];
-    }
-    float e0, e1;
-    if constexpr ((CE & 1) == 0) {
-        const f2 e = ld2(ev + j + CE);
-        e0 = e.x;
-        e1 = e.y;
-    } else {
-        e0 = ev[j + CE];
-        e1 = ev[j + CE + 1];
-    }
-    y0 = e0 + a0;
-    y1 = e1 + a1;
-}
 
 template <int TEAM>
 __device__ __forceinline__ float team_bcast(float v, int team_lane0, int tl)
@@ -114,16 +49,6 @@ __device__ __forceinline__ float team_sum(float v)
     for (int o = TEAM / 2; o > 0; o >>= 1)
         v += __shfl_xor(v, o, 64);
     return v;
-}
-
-__device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
-{
-    // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
-    const int m = step > job.is_m1 ? step : job.is_m1;
-    const int na = job.nb - m;
-    if (na <= 0)
-        return 1.0f;
-    return (float)exp2(0.5 * (double)na * job.log2_gamma);
 }
 
 // DETREND: 0 None, 1 Midpoint, 2 Span, 3 Mean (src/psd.rs:75-113).  EWMA: per-segment
@@ -183,24 +108,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
     constexpr int HR = (G::HIST + TEAM - 1) / TEAM;
     unsigned h_pack[HR];
 #pragma unroll
-    for (int r = 0; r < HR; ++r) {
-        const int i = tl + TEAM * r;
-        int front = -1, shift = 0;
-        if (i < 11) {
-            front = G::AE + i;
-            shift = N / 4;
-        } else if (i < 22) {
-            front = G::AO + (i - 11);
-            shift = N / 4;
-        } else if (i < 51) {
-            front = G::BE + (i - 22);
-            shift = N / 8;
-        } else if (i < 80) {
-            front = G::BO + (i - 51);
-            shift = N / 8;
-        }
-        h_pack[r] = front < 0 ? 0xFFFFu : ((unsigned)(front + shift) << 16) | (unsigned)front;
-    }
+    for (int r = 0; r < HR; ++r)
+        h_pack[r] = G::hist_slot(tl + TEAM * r);
 
     float q[16];
 #pragma unroll
@@ -409,8 +318,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
         wave_sync();
         T::load1(tl, v, frame);
         T::pass1(tl, v, s_tw1);
-        wave_sync();
-        T::store1(tl, v, frame);
+        T::store1(tl, v, frame); // in place: each lane rewrites exactly what it read
         wave_sync();
         T::load2(tl, v, frame);
         T::pass2(v);
@@ -451,7 +359,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
     }
 }
 
-bool fused_supported(int n) { return n == 256 || n == 512 || n == 1024; }
+bool fused_supported(int n)
+{
+    return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384;
+}
 
 int fused_pairs_per_block(int n, int run)
 {
@@ -463,7 +374,66 @@ int fused_pairs_per_block(int n, int run)
     case 1024:
         return FusedGeo<1024>::TEAMS * run;
     default:
-        return 0;
+        return fused_supported(n) ? run : 0; // one team (the whole workgroup) per workgroup
+    }
+}
+
+// resident workgroups the launch is sized for (per CU: LDS and thread limits of each size)
+int fused_max_blocks(int n)
+{
+    switch (n) {
+    case 2048:
+        return 256 * 4; // 128 threads, 17 KB of LDS, 2 wavefronts per SIMD
+    case 4096:
+        return 256 * 2; // 256 threads, 35 KB
+    case 8192:
+        return 256; // 512 threads, 70 KB
+    case 16384:
+        return 256; // 1024 threads, 139 KB
+    default:
+        return 512; // 8 wavefronts, <= 80 KB: two per CU
+    }
+}
+
+// global twiddle tables of the workgroup-level kernels: tw0[c * TEAM + tl] = W_N^(4 tl + c),
+// twa[(q - 1) * SA + s] = W_(N/4)^(s q)
+template <int N>
+static void big_tables_n(std::vector<cf> &tw0, std::vector<cf> &twa)
+{
+    using T = BlockFft<N>;
+    tw0.resize(T::TW0_SIZE);
+    twa.resize(T::TWA_SIZE);
+    for (int c = 0; c < 4; ++c)
+        for (int tl = 0; tl < T::TEAM; ++tl) {
+            const double a = -2.0 * M_PI * (double)(4 * tl + c) / (double)N;
+            tw0[c * T::TEAM + tl] = {(float)cos(a), (float)sin(a)};
+        }
+    for (int q = 1; q < T::RA; ++q)
+        for (int s2 = 0; s2 < T::SA; ++s2) {
+            const double a = -2.0 * M_PI * (double)(s2 * q) / (double)T::L1;
+            twa[(q - 1) * T::SA + s2] = {(float)cos(a), (float)sin(a)};
+        }
+}
+
+void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa)
+{
+    tw0.clear();
+    twa.clear();
+    switch (n) {
+    case 2048:
+        big_tables_n<2048>(tw0, twa);
+        break;
+    case 4096:
+        big_tables_n<4096>(tw0, twa);
+        break;
+    case 8192:
+        big_tables_n<8192>(tw0, twa);
+        break;
+    case 16384:
+        big_tables_n<16384>(tw0, twa);
+        break;
+    default:
+        break;
     }
 }
 
@@ -491,7 +461,12 @@ static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_fused(int n, const FusedBatch &b, const float *win, hipStream_t s)
+hipError_t launch_bigfused_2048(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
+hipError_t launch_bigfused_4096(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
+hipError_t launch_bigfused_8192(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
+hipError_t launch_bigfused_16384(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
+
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
@@ -502,6 +477,14 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, hipStream_
         return launch_fused_n<512>(b, win, s);
     case 1024:
         return launch_fused_n<1024>(b, win, s);
+    case 2048:
+        return launch_bigfused_2048(b, win, tw0g, twag, s);
+    case 4096:
+        return launch_bigfused_4096(b, win, tw0g, twag, s);
+    case 8192:
+        return launch_bigfused_8192(b, win, tw0g, twag, s);
+    case 16384:
+        return launch_bigfused_16384(b, win, tw0g, twag, s);
     default:
         return hipErrorInvalidValue;
     }

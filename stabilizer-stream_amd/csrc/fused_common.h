@@ -1,0 +1,121 @@
+// fused_common.h -- pieces shared by the team-level (fused.hip) and workgroup-level
+// (bigfused_impl.h) fused kernels: the stateful /8 half-band decimator geometry and its
+// two-outputs-per-lane evaluation, EWMA amplitude.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_core.h"
+#include "hbf_taps.h"
+#include "kernels.h"
+
+namespace psdk {
+
+// Decimator arrays inside a team's LDS frame (floats): [history | new], even/odd polyphase,
+// even sizes.  One pair = N new samples -> N/2 stage-A, N/4 stage-B, N/8 stage-C outputs.
+// Carried state: the last HA stage-A and HB stage-B outputs (the 12 input samples before the
+// new ones come from registers).  History sizes are chosen so that the polyphase offsets are
+// the same as in a stateless block with a 288-sample halo, which is what the warm-up at the
+// start of a run evaluates.
+template <int N>
+struct FusedDec {
+    static constexpr int HX = 12, HA = 22, HB = 58;
+    static constexpr int XE = 0, XO = XE + HX / 2 + N / 2;
+    static constexpr int AE = XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
+    static constexpr int BE = AO + 12 + N / 4, BO = BE + 30 + N / 8;
+    static constexpr int END = BO + 30 + N / 8;
+    static constexpr int HIST = HA + HB; // [0,11) AE, [11,22) AO, [22,51) BE, [51,80) BO
+    // warm-up block: WX samples before the first new one
+    static constexpr int WX = HBF_HALO, WA = HBF_PRE_A, WB = HBF_PRE_B; // 288, 138, 58
+    static constexpr int WXE = 0, WXO = WX / 2, WAE = WX, WAO = WX + WA / 2 + 1;
+    static constexpr int WEND = WAO + WA / 2 + 1;
+    // polyphase offsets: out j = ev[j + CE] + sum_i t[i] (od[j + CO + i] + od[j + CO + 2M-1-i])
+    static constexpr int A_CE = 4, A_CO = 1, B_CE = 6, B_CO = 0, C_CE = 15, C_CO = 0;
+    static_assert(HX / 2 - 2 == A_CE && HX / 2 - 5 == A_CO, "x history vs stage A offsets");
+    static_assert(HA / 2 - 5 == B_CE && HA / 2 - 11 == B_CO, "A history vs stage B offsets");
+    static_assert(HB / 2 - 14 == C_CE && HB / 2 - 29 == C_CO, "B history vs stage C offsets");
+    static_assert(WX / 2 - WA - HBF_MA + 1 == A_CE && WA / 2 - WB - HBF_MB + 1 == B_CE, "warm-up geometry");
+
+    // frame offsets of carried element i < HIST: where it is read from after a pair (tail) and
+    // where it must sit before the next one (front); packed tail << 16 | front
+    static __device__ __forceinline__ unsigned hist_slot(int i)
+    {
+        int front = -1, shift = 0;
+        if (i < 11) {
+            front = AE + i;
+            shift = N / 4;
+        } else if (i < 22) {
+            front = AO + (i - 11);
+            shift = N / 4;
+        } else if (i < 51) {
+            front = BE + (i - 22);
+            shift = N / 8;
+        } else if (i < 80) {
+            front = BO + (i - 51);
+            shift = N / 8;
+        }
+        return front < 0 ? 0xFFFFu : ((unsigned)(front + shift) << 16) | (unsigned)front;
+    }
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wavefront execute in order; this only stops the
+    // compiler from moving LDS accesses across the hand-off between lanes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
+
+// two consecutive outputs (j, j+1), j even, of a half-band stage with M unique taps:
+// out j = ev[j + CE] + sum_i taps[i] (od[j + CO + i] + od[j + CO + 2M-1-i]); odd array read
+// as aligned pairs.
+template <int M, int CE, int CO>
+__device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const float *__restrict__ od, int j,
+                                        const float (&taps)[M], float &y0, float &y1)
+{
+    constexpr int LO = CO & ~1;                // aligned start
+    constexpr int CNT = (CO - LO) + 2 * M + 1; // values needed from od[j + LO]
+    constexpr int NP = (CNT + 1) / 2;
+    float w[2 * NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const f2 v = ld2(od + j + LO + 2 * k);
+        w[2 * k] = v.x;
+        w[2 * k + 1] = v.y;
+    }
+    constexpr int O = CO - LO;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        a0 += (w[O + i] + w[O + 2 * M - 1 - i]) * taps[i];
+        a1 += (w[O + 1 + i] + w[O + 2 * M - i]) * taps[i];
+    }
+    float e0, e1;
+    if constexpr ((CE & 1) == 0) {
+        const f2 e = ld2(ev + j + CE);
+        e0 = e.x;
+        e1 = e.y;
+    } else {
+        e0 = ev[j + CE];
+        e1 = ev[j + CE + 1];
+    }
+    y0 = e0 + a0;
+    y1 = e1 + a1;
+}
+
+__device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
+{
+    // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
+    const int m = step > job.is_m1 ? step : job.is_m1;
+    const int na = job.nb - m;
+    if (na <= 0)
+        return 1.0f;
+    return (float)exp2(0.5 * (double)na * job.log2_gamma);
+}
+
+} // namespace psdk

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 #include "fft_core.h"
 
@@ -107,7 +108,6 @@ struct FusedBatch {
 #endif
 constexpr int FUSED_WAVES = PSDK_FUSED_WAVES;        // wavefronts per workgroup
 constexpr int FUSED_WAVES_PER_SIMD = PSDK_FUSED_WPS; // launch bound: wavefronts per SIMD
-constexpr int FUSED_MAX_BLOCKS = 512;   // 2 workgroups per CU (<= 80 KiB of LDS each, <= 128 VGPRs)
 
 // Carry the unconsumed tail of a stream to the front of its other buffer.
 struct TailJob {
@@ -128,9 +128,13 @@ constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 
 bool welch_supported(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
-bool fused_supported(int n);                 // N = 256, 512, 1024
+bool fused_supported(int n);                 // N = 256 ... 16384
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
-hipError_t launch_fused(int n, const FusedBatch &b, const float *win, hipStream_t s);
+int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
+// twiddle tables in global memory for the workgroup-level kernels (N >= 2048); empty otherwise
+void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa);
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag,
+                        hipStream_t s);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 pb += __shfl_xor(pb, o);
             }
             if constexpr (TEAM > 64) {
-                // one team per workgroup here: combine its waves through LDS
+                // a team spans TEAM / 64 wavefronts: combine exactly those through LDS
+                constexpr int WPT = TEAM / 64;
                 const int w = threadIdx.x >> 6;
                 if ((threadIdx.x & 63) == 0) {
                     red[2 * w] = pa;
@@ -153,9 +154,9 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 __syncthreads();
                 pa = 0.0f;
                 pb = 0.0f;
-                for (int i = 0; i < Cfg::WAVES; ++i) {
-                    pa += red[2 * i];
-                    pb += red[2 * i + 1];
+                for (int i = 0; i < WPT; ++i) {
+                    pa += red[2 * (team * WPT + i)];
+                    pb += red[2 * (team * WPT + i) + 1];
                 }
                 __syncthreads();
             }

@@ -82,6 +82,7 @@ struct psdc_handle {
     hipStream_t stream = nullptr;
     float *d_win = nullptr;
     cf *d_tw = nullptr;
+    cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
@@ -510,7 +511,7 @@ int advance_round(psdc_handle *h, bool *did_work)
             // workgroups in proportion to the pairs; every team of a job gets the same run
             FusedJob &j = fjobs[i].j;
             const uint64_t np = (uint64_t)j.npairs;
-            const uint64_t share = std::max<uint64_t>(1, (np * FUSED_MAX_BLOCKS + pairs / 2) / pairs);
+            const uint64_t share = std::max<uint64_t>(1, (np * (uint64_t)fused_max_blocks((int)h->n) + pairs / 2) / pairs);
             const uint64_t run = (np + share * teams - 1) / (share * teams);
             j.run = (int)run;
             j.nblocks = (int)((np + run * teams - 1) / (run * teams));
@@ -582,7 +583,7 @@ int advance_round(psdc_handle *h, bool *did_work)
         const bool first = (i <= (size_t)MAX_JOBS);
         if ((rc = prof_begin(pe)))
             return rc;
-        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->stream));
+        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->stream));
         if ((rc = prof_end(pe, first)))
             return rc;
     }
@@ -946,6 +947,17 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
         return dev_fail(e, "hipMalloc(tw)");
     if ((e = hipMalloc(&h->d_spectra, sizeof(float) * (size_t)n_channels * MAX_STAGES * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(spectra)");
+    {
+        std::vector<cf> t0, ta;
+        fused_big_tables((int)n, t0, ta);
+        if (!t0.empty()) {
+            if ((e = hipMalloc(&h->d_tw0g, sizeof(cf) * t0.size())) != hipSuccess ||
+                (e = hipMalloc(&h->d_twag, sizeof(cf) * ta.size())) != hipSuccess ||
+                (e = hipMemcpy(h->d_tw0g, t0.data(), sizeof(cf) * t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_twag, ta.data(), sizeof(cf) * ta.size(), hipMemcpyHostToDevice)) != hipSuccess)
+                return dev_fail(e, "twiddle tables");
+        }
+    }
     if ((e = hipMemcpy(h->d_win, win.data(), sizeof(float) * n, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(win)");
     if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
@@ -978,6 +990,10 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_win);
     if (h->d_tw)
         (void)hipFree(h->d_tw);
+    if (h->d_tw0g)
+        (void)hipFree(h->d_tw0g);
+    if (h->d_twag)
+        (void)hipFree(h->d_twag);
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;

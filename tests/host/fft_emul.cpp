@@ -5,6 +5,7 @@
 // 16-lane groups, 32 banks x 4 B).  Build: g++ -O2 -std=c++17 -I<csrc>.
 #include "fft_core.h"
 #include "fft_team.h"
+#include "fft_block.h"
 #include <cmath>
 #include <algorithm>
 #include <complex>
@@ -224,6 +225,118 @@ static int check_team()
     return (err < 2e-6) ? 0 : 1;
 }
 
+// workgroup FFT of the large-N fused kernel
+template <int N>
+static int check_block()
+{
+    using T = BlockFft<N>;
+    constexpr int TEAM = T::TEAM;
+    std::vector<cf> z(N), frame(T::FRAME), tw0(T::TW0_SIZE), twa(T::TWA_SIZE), twb(T::TWB_SIZE);
+    srand(11 + N);
+    for (int i = 0; i < N; ++i) {
+        z[i].re = (float)rand() / RAND_MAX - 0.5f;
+        z[i].im = (float)rand() / RAND_MAX - 0.5f;
+    }
+    for (int c = 0; c < 4; ++c)
+        for (int tl = 0; tl < TEAM; ++tl) {
+            double a = -2.0 * M_PI * (double)(4 * tl + c) / (double)N;
+            tw0[c * TEAM + tl] = {(float)cos(a), (float)sin(a)};
+        }
+    for (int q = 1; q < T::RA; ++q)
+        for (int s = 0; s < T::SA; ++s) {
+            double a = -2.0 * M_PI * (double)(s * q) / (double)T::L1;
+            twa[(q - 1) * T::SA + s] = {(float)cos(a), (float)sin(a)};
+        }
+    for (int q = 1; q < T::RB; ++q)
+        for (int s = 0; s < 16; ++s) {
+            double a = -2.0 * M_PI * (double)(s * q) / (double)T::SA;
+            twb[(q - 1) * 16 + s] = {(float)cos(a), (float)sin(a)};
+        }
+    std::vector<std::vector<cf>> regs(TEAM, std::vector<cf>(16));
+    for (int t = 0; t < TEAM; ++t)
+        for (int m = 0; m < 4; ++m)
+            for (int c = 0; c < 4; ++c)
+                regs[t][4 * m + c] = z[4 * t + c + (N / 4) * m];
+    for (int t = 0; t < TEAM; ++t) T::pass0(t, regs[t].data(), tw0.data());
+    for (int t = 0; t < TEAM; ++t) T::store0(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::loadA(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::passA(t, regs[t].data(), twa.data());
+    for (int t = 0; t < TEAM; ++t) T::storeA(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::loadB(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::passB(t, regs[t].data(), twb.data());
+    for (int t = 0; t < TEAM; ++t) T::storeB(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::loadC(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::passC(regs[t].data());
+    // reference via the f64 radix-2 of a simple recursive DFT (O(N log N) to keep N = 16384 quick)
+    std::vector<std::complex<double>> x(N), y(N);
+    for (int i = 0; i < N; ++i) x[i] = {z[i].re, z[i].im};
+    {   // iterative f64 FFT
+        int bits = 0;
+        while ((1 << bits) < N) ++bits;
+        for (int i = 0; i < N; ++i) {
+            int r = 0;
+            for (int b = 0; b < bits; ++b) if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+            y[r] = x[i];
+        }
+        for (int len = 2; len <= N; len <<= 1)
+            for (int b = 0; b < N; b += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    auto w = std::polar(1.0, -2.0 * M_PI * k / len);
+                    auto u = y[b + k], t = w * y[b + k + len / 2];
+                    y[b + k] = u + t;
+                    y[b + k + len / 2] = u - t;
+                }
+    }
+    std::vector<double> got(N, -1.0);
+    double err = 0, pmax = 0;
+    for (int k = 0; k < N; ++k) pmax = std::max(pmax, std::norm(y[k]));
+    for (int t = 0; t < TEAM; ++t)
+        for (int q = 0; q < 16; ++q) {
+            int k = T::freq_of(t, q);
+            if (k < 0 || k >= N || got[k] >= 0) {
+                printf("block<%d>: bad/duplicate k=%d\n", N, k);
+                return 1;
+            }
+            got[k] = (double)regs[t][q].re * regs[t][q].re + (double)regs[t][q].im * regs[t][q].im;
+        }
+    for (int k = 0; k < N; ++k) err = std::max(err, fabs(got[k] - std::norm(y[k])) / pmax);
+    long rd = 0, rdi = 0, wr = 0, wri = 0;
+    auto rd_instr = [&](auto addr) {
+        for (int w0 = 0; w0 < TEAM; w0 += 32) {
+            std::vector<int> sl;
+            for (int l = w0; l < w0 + 32; ++l) sl.push_back(addr(l));
+            rd += group_cycles(sl, 32), ++rdi;
+        }
+    };
+    auto wr_instr = [&](auto addr) {
+        for (int w0 = 0; w0 < TEAM; w0 += 16) {
+            std::vector<int> sl;
+            for (int l = w0; l < w0 + 16; ++l) sl.push_back(addr(l));
+            wr += group_cycles(sl, 16), ++wri;
+        }
+    };
+    for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 4; ++c)
+            wr_instr([&](int tl) { return 4 * tl + (tl >> 2) + T::STEP0 * q + c; });
+    for (int i = 0; i < T::NBA; ++i)
+        for (int m = 0; m < T::RA; ++m) {
+            auto a = [&](int tl) { return T::baseA(tl) + T::STEP0 * (TEAM / T::SA) * i + T::STEPA * m; };
+            rd_instr(a);
+            wr_instr(a);
+        }
+    for (int i = 0; i < T::NBB; ++i)
+        for (int m = 0; m < T::RB; ++m) {
+            auto a = [&](int tl) { return T::baseB(tl) + T::STEPA * i + 17 * m; };
+            rd_instr(a);
+            wr_instr(a);
+        }
+    for (int m = 0; m < 16; ++m)
+        rd_instr([&](int tl) { return 17 * tl + m; });
+    printf("block<%5d> (4,%2d,%2d,16): max|dP|/Pmax=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
+           N, T::RA, T::RB, err, rd, rdi, wr, wri);
+    return (err < 3e-6) ? 0 : 1;
+}
+
 int main()
 {
     int bad = 0;
@@ -242,6 +355,10 @@ int main()
     bad |= check_team<256>();
     bad |= check_team<512>();
     bad |= check_team<1024>();
+    bad |= check_block<2048>();
+    bad |= check_block<4096>();
+    bad |= check_block<8192>();
+    bad |= check_block<16384>();
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }

@@ -55,7 +55,8 @@ def check_against_oracle(pkg, ora, gpu, x_chunks, n, detrend="none", avg=None, w
 
 
 @pytest.mark.parametrize("n,total", [(16, 5000), (64, 40000), (256, 70001), (512, 65536),
-                                     (1024, 300000), (2048, 200000), (4096, 600000), (16384, 700000)])
+                                     (1024, 300000), (2048, 200000), (4096, 600000), (8192, 900000),
+                                     (16384, 2000000)])
 def test_cascade_parity_sizes(pkg, ora, gpu_required, n, total):
     x = make_signal(pkg, total, seed=100 + n, tone=0.5, dc=0.1)
     g = pkg.PsdCascadeBank(n)
@@ -65,7 +66,7 @@ def test_cascade_parity_sizes(pkg, ora, gpu_required, n, total):
 
 
 @pytest.mark.parametrize("detrend", ["none", "midpoint", "span", "mean"])
-@pytest.mark.parametrize("n", [64, 256, 512, 1024, 4096])
+@pytest.mark.parametrize("n", [64, 256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_detrend_parity(pkg, ora, gpu_required, n, detrend):
     x = make_signal(pkg, 40 * n + 123, seed=7 + n, tone=1.0, dc=3.0, f0=0.2 / n)
     g = pkg.PsdCascadeBank(n)
@@ -127,7 +128,7 @@ def test_chunking_invariance(pkg, ora, gpu_required):
     many.close()
 
 
-@pytest.mark.parametrize("n", [64, 256, 512, 1024])
+@pytest.mark.parametrize("n", [64, 256, 512, 1024, 4096])
 @pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (0xFFFFFFFF, 40), (5, 1000), (0, 7), (1, 1)])
 def test_ewma_parity(pkg, ora, gpu_required, limit, count, n):
     """Finite averaging (src/psd.rs:218-233, :431-436); n = 1024 runs the fused kernel's EWMA variant."""
@@ -292,7 +293,7 @@ def test_device_resident_input(pkg, ora, gpu_required):
     g2.close()
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize("detrend", ["none", "midpoint", "span", "mean"])
 def test_device_resident_detrend(pkg, ora, gpu_required, detrend, n):
     """Zero-copy spans through the fused kernel's variants (src/psd.rs:75-113), all fused sizes."""
