@@ -32,6 +32,7 @@ constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the
 thread_local std::string g_last_error;
 
 struct DevBuf {
+    bool pooled = false;              // p[] are slots of the handle's deep-stage pool (never freed singly)
     float *p[2] = {nullptr, nullptr}; // ping-pong: the tail is carried to the other buffer
     int cur = 0;
     size_t cap = 0;    // floats per buffer
@@ -87,6 +88,9 @@ struct psdc_handle {
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
     float *d_spectra = nullptr; // [n_channels][MAX_STAGES][n] accumulators, one slab
+    float *h_read = nullptr;    // pinned bounce buffer for read-outs (MAX_STAGES * n floats)
+    float *d_pool = nullptr;    // [n_channels][MAX_STAGES][2][pool_cap] small stream buffers (deep stages)
+    size_t pool_cap = 0;        // floats per pooled buffer
     bool idle = true;           // nothing ingested since the pipeline was last drained
     float *d_partial = nullptr;
     size_t partial_cap = 0; // floats
@@ -161,11 +165,13 @@ uint64_t keep_from(const Geometry &g, const StageState &s)
 
 int free_stage(psdc_handle *h, StageState &s)
 {
-    for (int i = 0; i < 2; ++i)
-        if (s.buf.p[i]) {
+    for (int i = 0; i < 2; ++i) {
+        if (s.buf.p[i] && !s.buf.pooled)
             HIPCHK(h, hipFree(s.buf.p[i]));
-            s.buf.p[i] = nullptr;
-        }
+        s.buf.p[i] = nullptr;
+    }
+    s.buf.pooled = false;
+    s.buf.cap = 0;
     s.spectrum = nullptr; // a slot of the handle's slab
     return PSDC_OK;
 }
@@ -178,6 +184,13 @@ int add_stage(psdc_handle *h, Channel &c)
     const size_t ci = (size_t)(&c - h->ch.data());
     s.spectrum = h->d_spectra + (ci * MAX_STAGES + c.st.size()) * h->n;
     HIPCHK(h, hipMemsetAsync(s.spectrum, 0, sizeof(float) * h->n, h->stream));
+    // every stream starts in the pre-allocated pool (enough for a deep stage's trickle); a stream
+    // that needs more moves to its own allocation in ensure_room
+    float *slot = h->d_pool + ((ci * MAX_STAGES + c.st.size()) * 2) * h->pool_cap;
+    s.buf.p[0] = slot;
+    s.buf.p[1] = slot + h->pool_cap;
+    s.buf.cap = h->pool_cap;
+    s.buf.pooled = true;
     c.st.push_back(s);
     return PSDC_OK;
 }
@@ -200,11 +213,12 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
     if (s.buf.p[0] || s.buf.p[1]) {
         HIPCHK(h, hipStreamSynchronize(h->stream)); // rare: only while buffers grow
         for (int i = 0; i < 2; ++i)
-            if (s.buf.p[i])
+            if (s.buf.p[i] && !s.buf.pooled)
                 HIPCHK(h, hipFree(s.buf.p[i]));
     }
     s.buf.p[0] = np[0];
     s.buf.p[1] = np[1];
+    s.buf.pooled = false;
     s.buf.cur = 0;
     s.buf.cap = cap;
     return PSDC_OK;
@@ -786,6 +800,23 @@ int flush_sync(psdc_handle *h)
     return PSDC_OK;
 }
 
+// device -> caller memory through the handle's pinned buffer (pageable D2H copies take a slow,
+// lazily initialised staging path in the runtime)
+int read_back(psdc_handle *h, float *dst, const float *d_src, size_t count)
+{
+    const size_t chunk = (size_t)MAX_STAGES * h->n;
+    while (count > 0) {
+        const size_t m = std::min(count, chunk);
+        HIPCHK(h, hipMemcpyAsync(h->h_read, d_src, sizeof(float) * m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        memcpy(dst, h->h_read, sizeof(float) * m);
+        dst += m;
+        d_src += m;
+        count -= m;
+    }
+    return PSDC_OK;
+}
+
 int check_channel(psdc_handle *h, uint32_t channel)
 {
     if (!h)
@@ -947,6 +978,24 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
         return dev_fail(e, "hipMalloc(tw)");
     if ((e = hipMalloc(&h->d_spectra, sizeof(float) * (size_t)n_channels * MAX_STAGES * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(spectra)");
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_read), sizeof(float) * (size_t)MAX_STAGES * n,
+                           hipHostMallocDefault)) != hipSuccess)
+        return dev_fail(e, "hipHostMalloc(read-out)");
+    // one full-size read through the pinned buffer now: the runtime initialises its device-to-host
+    // copy engine path lazily (several ms on the first copy above ~16 KB), which does not belong in
+    // the first psd() of a live stream
+    if ((e = hipMemsetAsync(h->d_spectra, 0, sizeof(float) * (size_t)MAX_STAGES * n, h->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(h->h_read, h->d_spectra, sizeof(float) * (size_t)MAX_STAGES * n, hipMemcpyDeviceToHost,
+                            h->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(h->stream)) != hipSuccess)
+        return dev_fail(e, "read-out warm-up");
+    h->pool_cap = (size_t)4 * (n + HBF_HALO) + 64;
+    if ((e = hipMalloc(&h->d_pool, sizeof(float) * (size_t)n_channels * MAX_STAGES * 2 * h->pool_cap)) != hipSuccess)
+        return dev_fail(e, "hipMalloc(stream pool)");
+    // partial slab for a full round (grows only if many channels need more)
+    h->partial_cap = (size_t)(fused_max_blocks((int)n) + WELCH_MAX_BLOCKS + 4 * MAX_JOBS) * n;
+    if ((e = hipMalloc(&h->d_partial, sizeof(float) * h->partial_cap)) != hipSuccess)
+        return dev_fail(e, "hipMalloc(partials)");
     {
         std::vector<cf> t0, ta;
         fused_big_tables((int)n, t0, ta);
@@ -982,6 +1031,10 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_partial);
     if (h->d_spectra)
         (void)hipFree(h->d_spectra);
+    if (h->d_pool)
+        (void)hipFree(h->d_pool);
+    if (h->h_read)
+        (void)hipHostFree(h->h_read);
     if (h->d_frames)
         (void)hipFree(h->d_frames);
     if (h->h_frames)
@@ -1358,8 +1411,7 @@ int psdc_stage_spectrum(psdc_handle *h, uint32_t channel, uint32_t stage, float 
     Channel &c = h->ch[channel];
     if (stage >= c.st.size())
         return fail(h, PSDC_ERR_ARG, "stage out of range");
-    HIPCHK(h, hipMemcpy(out, c.st[stage].spectrum, sizeof(float) * (h->n / 2 + 1), hipMemcpyDeviceToHost));
-    return PSDC_OK;
+    return read_back(h, out, c.st[stage].spectrum, h->n / 2 + 1);
 }
 
 int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out)
@@ -1400,8 +1452,9 @@ int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out,
         return fail(h, PSDC_ERR_CAPACITY, "output too small");
     if (pend) {
         const uint64_t from = s.total - pend;
-        HIPCHK(h, hipMemcpy(out, s.buf.p[s.buf.cur] + (from - s.buf.base), sizeof(float) * pend,
-                            hipMemcpyDeviceToHost));
+        rc = read_back(h, out, s.buf.p[s.buf.cur] + (from - s.buf.base), (size_t)pend);
+        if (rc)
+            return rc;
     }
     return PSDC_OK;
 }
@@ -1431,11 +1484,12 @@ int psdc_read_channel(psdc_handle *h, uint32_t channel, uint32_t cap, uint32_t *
             stats[k].processed = (uint64_t)h->n * s.count - (uint64_t)h->geo.overlap * cm1;
         }
     if (spectra && ns) { // the channel's accumulators are consecutive rows of one slab: one copy
-        std::vector<float> rows((size_t)ns * h->n);
-        HIPCHK(h, hipMemcpy(rows.data(), c.st[0].spectrum, sizeof(float) * rows.size(), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpyAsync(h->h_read, c.st[0].spectrum, sizeof(float) * (size_t)ns * h->n,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         const size_t bins = h->n / 2 + 1;
         for (uint32_t k = 0; k < ns; ++k)
-            memcpy(spectra + k * bins, rows.data() + (size_t)k * h->n, sizeof(float) * bins);
+            memcpy(spectra + k * bins, h->h_read + (size_t)k * h->n, sizeof(float) * bins);
     }
     return PSDC_OK;
 }
@@ -1462,10 +1516,11 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
         pend[i] = pending_for(h->geo, c.st[i].total);
     }
     if (psd_out && ns) {
-        std::vector<float> rows(ns * h->n);
-        HIPCHK(h, hipMemcpy(rows.data(), c.st[0].spectrum, sizeof(float) * rows.size(), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpyAsync(h->h_read, c.st[0].spectrum, sizeof(float) * ns * h->n, hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         for (size_t i = 0; i < ns; ++i)
-            memcpy(spectra.data() + i * bins, rows.data() + i * h->n, sizeof(float) * bins);
+            memcpy(spectra.data() + i * bins, h->h_read + i * h->n, sizeof(float) * bins);
     }
     rc = stitch_impl(h->n, h->nenbw, h->power, h->geo.overlap, (uint32_t)ns, counts.data(), avgs.data(),
                      pend.data(), spectra.data(), keep_overlap, min_count, keep_transition_band, psd_out,

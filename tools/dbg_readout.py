@@ -3,11 +3,11 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import __graft_entry__ as entry
 import torch, numpy as np
 pkg = entry.load_package()
-n, T = 1024, 1 << 26
+n, T = int(os.environ.get("PSD_N", "1024")), 1 << 26
 bank = pkg.PsdCascadeBank(n, 1)
 d = torch.empty(T, dtype=torch.float32, device="cuda")
 pkg.fill_noise_device(d.data_ptr(), T, seed=1)
-for _ in range(20):
+for _ in range(63):
     bank.process_device(0, d.data_ptr(), T)
 bank.sync()
 def tm(label, f):
