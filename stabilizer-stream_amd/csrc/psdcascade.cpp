@@ -282,7 +282,7 @@ int collect_profile(psdc_handle *h)
 // next round (stage k+1 lags one round behind stage k), so a round costs one
 // welch, one reduce, one decimator and one tail launch whatever the depth.
 // *did_work tells whether anything was issued; read-outs call rounds until idle.
-int advance_round(psdc_handle *h, bool *did_work)
+int advance_round(psdc_handle *h, bool *did_work, bool all)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
@@ -328,7 +328,12 @@ int advance_round(psdc_handle *h, bool *did_work)
         Channel &c = h->ch[ci];
         for (uint32_t k = 0; k < c.st.size(); ++k) {
             StageState &s = c.st[k];
-            const uint64_t j_new = segments_for(g, s.total);
+            uint64_t j_new = segments_for(g, s.total);
+            // ingest path (all == false): a decimated stage issues whole segment pairs only, the odd
+            // segment waits for its partner -- it would cost a launch of the generic kernels every
+            // other round; read-outs (all == true) issue everything
+            if (!all && fast_ok && k >= 1 && ((j_new - s.segs) & 1))
+                j_new -= 1;
             if (j_new == s.segs)
                 continue;
             Work w;
@@ -562,7 +567,7 @@ int advance_round(psdc_handle *h, bool *did_work)
 
     // ---- launches: fused, generic welch, reduce, generic decimator -------
     // HIP events bracket the dominant kernel of the round (fused when present)
-    const bool prof_fused = !fjobs.empty();
+    const bool prof_fused = fast_ok; // the handle's dominant kernel kind, not the round's
     auto prof_begin = [&](ProfEvents &pe) -> int {
         if (!h->profile)
             return PSDC_OK;
@@ -701,7 +706,7 @@ int advance_round(psdc_handle *h, bool *did_work)
 int advance(psdc_handle *h)
 {
     bool did = false;
-    return advance_round(h, &did);
+    return advance_round(h, &did, false);
 }
 
 // rounds until the pipeline is idle (read-out path)
@@ -711,7 +716,7 @@ int drain(psdc_handle *h)
         return PSDC_OK;
     for (int guard = 0; guard < 64; ++guard) {
         bool did = false;
-        int rc = advance_round(h, &did);
+        int rc = advance_round(h, &did, true);
         if (rc)
             return rc;
         if (!did) {

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc/bench_$c.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc/bench_$c.log 2>&1
   rc=$?
   echo "$c rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 $GRAFT_REPO_ROOT/gpurun_out/pmc/bench_$c.log; exit $rc; fi
