@@ -17,8 +17,10 @@ or tests/conftest.py (module name `stabilizer_stream_amd`).
 """
 import ctypes as C
 import enum
+import importlib.util
 import os
 import subprocess
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -149,6 +151,25 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so; if
+    libpsdcascade.so were loaded first it would bind /opt/rocm's copy, torch would later bring its
+    own, and whichever initialises second finds "no ROCm-capable device".  So when torch is
+    installed but not imported yet, load the runtime it will use (same SONAME) before our library;
+    no torch import is forced on callers that never use it."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load the C-ABI library.  Fails loudly if it has not been built."""
     global _lib
@@ -157,6 +178,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
                           "(there is no Python/CPU fallback for the PSD kernels)")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     H, u32, u64, i32, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
     fp = C.POINTER(C.c_float)

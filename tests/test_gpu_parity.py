@@ -415,3 +415,67 @@ def test_full_size_properties(pkg, gpu_required):
         assert np.array_equal(g3.stage_spectrum(0, k), 16.0 * g.stage_spectrum(0, k))
     for h in (g, g2, g3):
         h.close()
+
+
+@pytest.mark.parametrize("n,seed", [(256, 1), (512, 2), (1024, 3), (1024, 4), (2048, 5), (64, 6)])
+def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
+    """Seeded random mix of everything the boundary allows: host and in-place device feeding with odd
+    lengths and alignments, tiny and large spans, mid-stream read-outs, detrend / averaging changes,
+    several channels fed unevenly -- each channel must track its oracle cascade throughout."""
+    import torch
+    rng = np.random.default_rng(seed)
+    nch = 3
+    total = int(rng.integers(60, 140)) * n * 8
+    xs = [make_signal(pkg, total, seed=100 * seed + c, tone=0.3 * c, dc=0.2 * c) for c in range(nch)]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, nch)
+    g.configure(quantum=int(rng.integers(2, 20)) * n)
+    refs = [ora.PsdCascade(n, "f64") for _ in range(nch)]
+    pos = [0] * nch
+    detrends = ["none", "midpoint", "span", "mean"]
+    while min(pos) < total:
+        c = int(rng.integers(0, nch))
+        if pos[c] >= total:
+            c = int(np.argmin(pos))
+        kind = rng.random()
+        if kind < 0.08:  # settings change (applies to segments completed afterwards, all channels)
+            d = detrends[int(rng.integers(0, 4))]
+            g.set_detrend(pkg.Detrend[d.upper()])
+            for r in refs:
+                r.set_detrend(d)
+            continue
+        if kind < 0.12:
+            lim, cnt = int(rng.integers(1, 50)), int(rng.integers(1, 400))
+            g.set_avg(pkg.AvgOpts(lim, cnt))
+            for r in refs:
+                r.set_avg(lim, cnt)
+            continue
+        if kind < 0.2:  # mid-stream read-out of one channel
+            cc = int(rng.integers(0, nch))
+            infos, sp = g.read_channel(cc)
+            assert len(infos) == refs[cc].num_stages
+            for k, info in enumerate(infos):
+                assert info == refs[cc].stage_info(k), (cc, k)
+            continue
+        m = int(rng.choice([rng.integers(1, 50), rng.integers(1, 6 * n), rng.integers(6 * n, 40 * n)]))
+        m = min(m, total - pos[c])
+        a, b = pos[c], pos[c] + m
+        if rng.random() < 0.5:
+            g.process(c, xs[c][a:b])
+        else:
+            g.process_device(c, xd[c].data_ptr() + 4 * a, m)
+        refs[c].process(xs[c][a:b])
+        pos[c] = b
+    for c in range(nch):
+        ns = g.num_stages(c)
+        assert ns == refs[c].num_stages
+        for k in range(ns):
+            assert g.stage_info(c, k) == refs[c].stage_info(k), (c, k)
+            if refs[c].stage_info(k)["count"]:
+                assert_psd_close(g.stage_spectrum(c, k), refs[c].stage_spectrum(k), f"ch {c} stage {k}")
+            gb, rb = g.stage_buf(c, k), refs[c].stage_buf(k)
+            assert gb.shape == rb.shape
+            if rb.size:
+                assert np.max(np.abs(gb - rb)) <= 1e-5 * max(1e-3, float(np.max(np.abs(rb))))
+    g.close()
