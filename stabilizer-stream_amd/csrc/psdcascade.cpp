@@ -279,9 +279,12 @@ int collect_profile(psdc_handle *h)
 // One round of the cascade pipeline: every (channel, stage) that has complete
 // segments in its stream buffer is issued, all stages in the SAME launches.
 // The decimator output of this round becomes visible to the next stage in the
-// next round (stage k+1 lags one round behind stage k), so a round costs one
-// welch, one reduce, one decimator and one tail launch whatever the depth.
-// *did_work tells whether anything was issued; read-outs call rounds until idle.
+// next round (stage k+1 lags one round behind stage k), so a steady-state round
+// costs a seam copy, one fused launch and one post launch whatever the depth
+// (plus the generic welch / decimator kernels when something does not fit a pair).
+// `all`: issue odd segments of decimated stages too (read-outs); the ingest path
+// leaves them for their partner.  *did_work tells whether anything was issued;
+// read-outs call rounds until idle.
 int advance_round(psdc_handle *h, bool *did_work, bool all)
 {
     const Geometry &g = h->geo;

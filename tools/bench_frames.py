@@ -1,0 +1,24 @@
+"""BASELINE config 3: 4-channel dual-iir (AdcDac) frame stream, N=4096, 50 % overlap, one GPU.
+Frames live in host memory (as read from a frame file / UDP); rate = samples of all 4 traces per second."""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import __graft_entry__ as entry
+pkg = entry.load_package()
+n, batches = 4096, 22
+nframes = 95325  # ~2^24 samples per channel
+rng = np.random.default_rng(1)
+raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8)) * 4096), -32768, 32767).astype(np.int16)
+data, fs = pkg.make_adcdac_frames(raw, batches)
+g = pkg.PsdCascadeBank(n, 4)
+g.process_adcdac_frames(data, fs)
+g.sync()
+reps = 10
+t0 = time.perf_counter()
+for _ in range(reps):
+    g.process_adcdac_frames(data, fs)
+g.sync()
+dt = time.perf_counter() - t0
+samples = reps * raw.size
+print(f"frames path: {samples / dt / 1e6:.0f} MS/s over 4 traces ({len(data) * reps / dt / 1e9:.2f} GB/s of frame bytes), "
+      f"{g.num_stages(0)} stages, loss {g.loss()}")
