@@ -78,7 +78,7 @@ struct BlockFft {
         for (int i = 0; i < NBA; ++i)
 #pragma unroll
             for (int m = 0; m < RA; ++m)
-                v[RA * i + m] = base[STEP0 * (TEAM / SA) * i + STEPA * m];
+                v[RA * i + m] = lds_ld(base + STEP0 * (TEAM / SA) * i + STEPA * m);
     }
     // twa[(q-1) * SA + s] = W_L1^(s q)
     static PSDK_HD void passA(int tl, cf *v, const cf *twa)
@@ -112,9 +112,9 @@ struct BlockFft {
         for (int i = 0; i < NBB; ++i)
 #pragma unroll
             for (int m = 0; m < RB; ++m)
-                v[RB * i + m] = base[STEPA * i + 17 * m];
+                v[RB * i + m] = lds_ld(base + STEPA * i + 17 * m);
     }
-    // twb[(q-1) * 16 + s] = W_SA^(s q)
+    // twb[(q-1) * 16 + s] = W_SA^(s q), in LDS
     static PSDK_HD void passB(int tl, cf *v, const cf *twb)
     {
         const int s = tl & 15;
@@ -123,7 +123,7 @@ struct BlockFft {
             Dft<RB>::run(v + RB * i);
 #pragma unroll
             for (int q = 1; q < RB; ++q)
-                v[RB * i + q] = cmul(v[RB * i + q], twb[(q - 1) * 16 + s]);
+                v[RB * i + q] = cmul(v[RB * i + q], lds_ld(twb + (q - 1) * 16 + s));
         }
     }
     static PSDK_HD void storeB(int tl, const cf *v, cf *frame)
@@ -142,7 +142,7 @@ struct BlockFft {
         const cf *base = frame + 17 * tl;
 #pragma unroll
         for (int m = 0; m < 16; ++m)
-            v[m] = base[m];
+            v[m] = lds_ld(base + m);
     }
     static PSDK_HD void passC(cf *v) { Dft<16>::run(v); }
 };

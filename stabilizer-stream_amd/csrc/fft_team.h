@@ -44,7 +44,7 @@ struct TeamFft {
         for (int c = 0; c < 4; ++c) {
             cf b[4] = {v[c], v[4 + c], v[8 + c], v[12 + c]};
             Dft<4>::run(b);
-            const cf w1 = tw0[c * TEAM + tl];
+            const cf w1 = lds_ld(tw0 + c * TEAM + tl);
             const cf w2 = cmul(w1, w1);
             const cf w3 = cmul(w2, w1);
             v[c] = b[0];
@@ -79,7 +79,7 @@ struct TeamFft {
         for (int i = 0; i < NB1; ++i)
 #pragma unroll
             for (int m = 0; m < R1; ++m)
-                v[R1 * i + m] = base[STEP1 * i + 17 * m];
+                v[R1 * i + m] = lds_ld(base + STEP1 * i + 17 * m);
     }
     static PSDK_HD void pass1(int tl, cf *v, const cf *tw1)
     {
@@ -89,7 +89,7 @@ struct TeamFft {
             Dft<R1>::run(v + R1 * i);
 #pragma unroll
             for (int q = 1; q < R1; ++q)
-                v[R1 * i + q] = cmul(v[R1 * i + q], tw1[(q - 1) * 16 + s]);
+                v[R1 * i + q] = cmul(v[R1 * i + q], lds_ld(tw1 + (q - 1) * 16 + s));
         }
     }
     static PSDK_HD void store1(int tl, const cf *v, cf *frame)
@@ -108,7 +108,7 @@ struct TeamFft {
         const cf *base = frame + 17 * tl; // swz(16 tl + m) = 17 tl + m
 #pragma unroll
         for (int m = 0; m < 16; ++m)
-            v[m] = base[m];
+            v[m] = lds_ld(base + m);
     }
     static PSDK_HD void pass2(cf *v) { Dft<16>::run(v); }
 };

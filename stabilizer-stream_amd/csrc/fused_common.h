@@ -69,7 +69,12 @@ __device__ __forceinline__ void wave_sync()
 struct f2 {
     float x, y;
 };
-__device__ __forceinline__ f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
+// aligned 8-byte LDS read, kept a single ds_read_b64 (see lds_ld in fft_core.h)
+__device__ __forceinline__ f2 ld2(const float *p)
+{
+    const cf v = lds_ld(reinterpret_cast<const cf *>(p));
+    return {v.re, v.im};
+}
 
 // two consecutive outputs (j, j+1), j even, of a half-band stage with M unique taps:
 // out j = ev[j + CE] + sum_i taps[i] (od[j + CO + i] + od[j + CO + 2M-1-i]); odd array read
