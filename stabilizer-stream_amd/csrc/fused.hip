@@ -25,6 +25,24 @@
 
 namespace psdk {
 
+// -DPSDK_STAMPS (tools/stamps): the first wavefront of workgroup 0 sums the s_memtime ticks it
+// spends in each phase of pair_step into g_stamps; never defined in the shipped build.
+#ifdef PSDK_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define PSDK_STAMP(k)                                                \
+    do {                                                             \
+        if (stamp_on) {                                              \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+            st[k] += t_ - tprev;                                     \
+            tprev = t_;                                              \
+        }                                                            \
+    } while (0)
+#else
+#define PSDK_STAMP(k) \
+    do {              \
+    } while (0)
+#endif
+
 template <int N>
 struct FusedGeo : FusedDec<N> {
     using T = TeamFft<N>;
@@ -117,11 +135,20 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
         q[s] = 0.0f;
 
     __syncthreads(); // tables ready
+#ifdef PSDK_STAMPS
+    const bool stamp_on = wb == 0 && run >= 8 && tid < 64; // first workgroup of a long-run job
+    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
 
-    // this team's run: pairs [p0, p0 + run) of the job (possibly cut by npairs)
+    // this team's run: pairs [p0, p0 + nrun) of the job (the job's last teams get fewer or none)
     const int p0 = (wb * TEAMS + team) * run;
-    const bool act0 = p0 < npairs;
+    const int nrun = min(run, npairs - p0);
+    const bool act0 = nrun > 0;
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tl;
+    // where the look-ahead loads go once there is nothing left to look ahead to: pieces that were
+    // read before (every job holds at least one pair = 3N/2 samples)
+    const float4 *safe = act0 ? cp : reinterpret_cast<const float4 *>(job.src) + tl;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ga[2] = {z4, z4}, gb[2] = {z4, z4}, gc[2] = {z4, z4};
     if (act0) { // chunk p0 (all of it exists) and the lower half of chunk p0 + 1
@@ -175,30 +202,34 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
     // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
     // chunk p + 2 into `lo`, in flight during the FFT passes.  For pair p + 1 the roles are
     // (lo, up, nl) <- (nl, up, lo).
-    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool act,
-                         bool more, float *o, int p) {
+    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool more,
+                         float *o, int p) {
         // ---- decimator ------------------------------------------------------------------
+        PSDK_STAMP(0);
 #pragma unroll
         for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
                 sf[h_pack[r] & 0xFFFFu] = hs[tl + TEAM * r];
-        if (tl >= TEAM - 3) { // the 12 samples before the new ones (end of chunk p's lower half)
-            const int h = 2 * (tl - (TEAM - 3));
-            *reinterpret_cast<f2 *>(sf + G::XE + h) = {lo[1].x, lo[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h) = {lo[1].y, lo[1].w};
-        }
+        // samples -> polyphase arrays as single floats: pairs of them leave as ds_write2_b32 from
+        // whatever registers the loads delivered them to (an 8-byte store of {x, z} would need the
+        // two in adjacent registers, i.e. moves right behind the loads)
+        auto split = [&](int h, const float4 &x) {
+            sf[G::XE + h] = x.x;
+            sf[G::XE + h + 1] = x.z;
+            sf[G::XO + h] = x.y;
+            sf[G::XO + h + 1] = x.w;
+        };
+        if (tl >= TEAM - 3) // the 12 samples before the new ones (end of chunk p's lower half)
+            split(2 * (tl - (TEAM - 3)), lo[1]);
         {
             const int h = G::HX / 2 + 2 * tl;
-            *reinterpret_cast<f2 *>(sf + G::XE + h) = {up[0].x, up[0].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h) = {up[0].y, up[0].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 8) = {up[1].x, up[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 8) = {up[1].y, up[1].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 4) = {nl[0].x, nl[0].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 4) = {nl[0].y, nl[0].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + 3 * N / 8) = {nl[1].x, nl[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + 3 * N / 8) = {nl[1].y, nl[1].w};
+            split(h, up[0]);
+            split(h + N / 8, up[1]);
+            split(h + N / 4, nl[0]);
+            split(h + 3 * N / 8, nl[1]);
         }
         wave_sync();
+        PSDK_STAMP(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, (2u, 2u+1) -> AE/AO[11 + u]
             const int u = tl + TEAM * r;
@@ -208,6 +239,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             sf[G::AO + 11 + u] = y1;
         }
         wave_sync();
+        PSDK_STAMP(2);
 #pragma unroll
         for (int r = 0; r < 2; ++r) { // stage B: N/4 outputs -> BE/BO[29 + u]
             const int u = tl + TEAM * r;
@@ -217,19 +249,18 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             sf[G::BO + 29 + u] = y1;
         }
         wave_sync();
+        PSDK_STAMP(3);
         { // stage C: N/8 outputs, two per lane, straight to the next stage's stream
             float y0, y1;
             hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tl, tc, y0, y1);
-            if (act) {
-                o[2 * tl] = y0;
-                o[2 * tl + 1] = y1;
-            }
+            *reinterpret_cast<f2 *>(o + 2 * tl) = {y0, y1};
         }
 #pragma unroll
         for (int r = 0; r < HR; ++r) // tails of A and B -> carried state
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
                 hs[tl + TEAM * r] = sf[h_pack[r] >> 16];
         wave_sync(); // the frame is reused by the FFT
+        PSDK_STAMP(4);
 
         // ---- FFT of the pair: re = segment 2p, im = segment 2p + 1 -------------------------
         cf v[16];
@@ -305,44 +336,56 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
             put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
         }
-        if (more) { // pair p + 1 exists for this team: chunk p + 1 upper -> up, chunk p + 2 lower -> lo
-            up[0] = cnext[2 * TEAM];
-            up[1] = cnext[3 * TEAM];
-            lo[0] = cnext[N / 4];
-            lo[1] = cnext[N / 4 + TEAM];
-        } else {
-            up[0] = up[1] = lo[0] = lo[1] = z4;
+        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT.  Issued
+          // unconditionally (after the last pair: re-reads, unused) -- a load under a branch is
+          // waited for at the branch's end, which would expose the HBM latency once per pair.
+            const float4 *src = more ? cnext : safe;
+            safe = src;
+            up[0] = src[2 * TEAM];
+            up[1] = src[3 * TEAM];
+            lo[0] = src[N / 4];
+            lo[1] = src[N / 4 + TEAM];
         }
+        PSDK_STAMP(5);
         T::pass0(tl, v, s_tw0);
         T::store0(tl, v, frame);
         wave_sync();
+        PSDK_STAMP(6);
         T::load1(tl, v, frame);
         T::pass1(tl, v, s_tw1);
         T::store1(tl, v, frame); // in place: each lane rewrites exactly what it read
         wave_sync();
+        PSDK_STAMP(7);
         T::load2(tl, v, frame);
         T::pass2(v);
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
         wave_sync(); // next pair's decimator writes the frame
+        PSDK_STAMP(8);
     };
 
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
-        for (int i = 0; i < run; i += 2) {
-            const int p = p0 + i;
-            pair_step(ga, gb, gc, cp + N / 4, p < npairs, (i + 1 < run) && (p + 1 < npairs), o, p);
+        for (int i = 0; i < nrun; i += 2) {
+            pair_step(ga, gb, gc, cp + N / 4, i + 1 < nrun, o, p0 + i);
             cp += N / 4;
             o += N / 8;
-            if (i + 1 < run) {
-                pair_step(gc, gb, ga, cp + N / 4, p + 1 < npairs, (i + 2 < run) && (p + 2 < npairs), o, p + 1);
+            if (i + 1 < nrun) {
+                pair_step(gc, gb, ga, cp + N / 4, i + 2 < nrun, o, p0 + i + 1);
                 cp += N / 4;
                 o += N / 8;
             }
         }
     }
 
+#ifdef PSDK_STAMPS
+    if (stamp_on && tid == 0) {
+        for (int k = 0; k < 12; ++k)
+            g_stamps[k] = st[k];
+        g_stamps[12] = (unsigned long long)run;
+    }
+#endif
     // combine the teams; partial in natural bin order
 #pragma unroll
     for (int s = 0; s < 16; ++s)
@@ -491,3 +534,10 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
 }
 
 } // namespace psdk
+
+#ifdef PSDK_STAMPS
+extern "C" int psdc_debug_stamps(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(psdk::g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
