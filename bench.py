@@ -66,7 +66,8 @@ def host_fed_rate(pkg, n, device, seconds=2.0):
     dt = time.perf_counter() - t0
     bank.close()
     return {"value": done / dt / 1e6, "unit": "MS/s",
-            "note": "host numpy buffer -> psdc_process (memcpy to pinned staging + hipMemcpyAsync + kernels), 1 host thread"}
+            "note": "host numpy buffer -> psdc_process (copy to pinned staging split over <= 4 host threads, "
+                    "hipMemcpyAsync, kernels); link-bound"}
 
 
 def measured_traffic(kernel):
@@ -192,7 +193,7 @@ def main():
         kern_s = prof["kernel_ms"] * 1e-3
         ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
-        kname = "fused_kernel" if n in (256, 512, 1024) else "welch_kernel"
+        kname = "fused_kernel" if n in (256, 512, 1024) else ("bigfused_kernel" if n <= 16384 and n >= 2048 else "welch_kernel")
         tr = measured_traffic(kname) if (C == 1 and args.log2_batch == 26) else None
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,

@@ -12,11 +12,15 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hbf_taps.h"
@@ -94,10 +98,17 @@ struct psdc_handle {
     bool idle = true;           // nothing ingested since the pipeline was last drained
     float *d_partial = nullptr;
     size_t partial_cap = 0; // floats
-    uint8_t *d_frames = nullptr;
-    size_t frames_cap = 0;
-    uint8_t *h_frames = nullptr; // pinned
-    size_t h_frames_cap = 0;
+    // epilogue of the last round (fold the partials into the spectra, carry the stream tails),
+    // not launched yet: it rides in the first launch of the next round or of a read-out
+    std::vector<RedJob> pend_red;
+    std::vector<TailJob> pend_tail;
+    // frame ingest: two pinned bounce buffers and their device images, used alternately
+    uint8_t *d_frames[2] = {nullptr, nullptr};
+    uint8_t *h_frames[2] = {nullptr, nullptr};
+    hipEvent_t frames_ev[2] = {nullptr, nullptr}; // H2D of the buffer finished
+    bool frames_ev_pending[2] = {false, false};
+    size_t frames_cap = 0; // bytes per buffer
+    int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
     bool profile = false;
     std::vector<ProfEvents> prof_pending;
@@ -123,6 +134,123 @@ int fail(psdc_handle *h, int code, const std::string &msg)
             return fail(h, PSDC_ERR_DEVICE,                                                      \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
+
+// Host samples reach the device through pinned staging buffers.  One core copies ~34 GB/s into
+// pinned memory while the link takes ~55 GB/s, so large copies are split over a few threads
+// (PSDC_COPY_THREADS, default 4, 1 = caller only).  The workers are created on first use and
+// shared by all handles; a copy that finds them busy is done by its caller alone.
+class CopyPool {
+public:
+    static CopyPool &get()
+    {
+        static CopyPool p;
+        return p;
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        constexpr size_t kMin = (size_t)2 << 20;
+        if (bytes < kMin || nthreads_ <= 1 || !busy_.try_lock()) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        start_workers();
+        const size_t nw = th_.size();
+        if (nw == 0) {
+            busy_.unlock();
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t part = ((bytes / (nw + 1)) + 4095) & ~(size_t)4095;
+        char *d = static_cast<char *>(dst);
+        const char *sp = static_cast<const char *>(src);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t i = 0; i < nw; ++i) {
+                const size_t o = std::min(bytes, part * (i + 1));
+                parts_[i] = {d + o, sp + o, std::min(part, bytes - o)};
+            }
+            pending_ = (int)nw;
+            ++gen_;
+        }
+        cv_.notify_all();
+        memcpy(d, sp, std::min(part, bytes));
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait(lk, [&] { return pending_ == 0; });
+        }
+        busy_.unlock();
+    }
+
+private:
+    struct Part {
+        char *d;
+        const char *s;
+        size_t n;
+    };
+    CopyPool()
+    {
+        int n = 4;
+        if (const char *e = getenv("PSDC_COPY_THREADS"))
+            n = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0)
+            n = std::min(n, hw);
+        nthreads_ = std::max(1, std::min(n, 16));
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_)
+            t.join();
+    }
+    void start_workers()
+    {
+        if (started_)
+            return;
+        started_ = true;
+        parts_.resize((size_t)nthreads_ - 1);
+        try {
+            for (int i = 0; i + 1 < nthreads_; ++i)
+                th_.emplace_back([this, i] { worker((size_t)i); });
+        } catch (...) { // no more threads: the ones that started (possibly none) do the work
+        }
+        parts_.resize(th_.size());
+    }
+    void worker(size_t id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            Part p;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_)
+                    return;
+                seen = gen_;
+                p = id < parts_.size() ? parts_[id] : Part{nullptr, nullptr, 0};
+            }
+            if (p.n)
+                memcpy(p.d, p.s, p.n);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0)
+                    done_cv_.notify_one();
+            }
+        }
+    }
+    int nthreads_ = 1;
+    bool started_ = false, stop_ = false;
+    std::vector<std::thread> th_;
+    std::vector<Part> parts_;
+    std::mutex m_, busy_;
+    std::condition_variable cv_, done_cv_;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+};
 
 struct WindowConsts {
     float nenbw, power;
@@ -195,12 +323,39 @@ int add_stage(psdc_handle *h, Channel &c)
     return PSDC_OK;
 }
 
+// The epilogue of a round -- fold its partials (RedJob), carry its stream tails (TailJob) -- is
+// not launched when the round ends: the next round starts with a copy launch of its own (the
+// zero-copy seams), and one launch does both.  Nothing on the device reads what the epilogue
+// writes before that point; host-visible state never waits for it (read-outs drain first).
+int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
+{
+    const size_t nr = h->pend_red.size(), np = h->pend_tail.size(), nt = np + extra.size();
+    for (size_t ri = 0, ti = 0; ri < nr || ti < nt;) {
+        RedBatch rb{};
+        rb.n = (int)h->n;
+        for (; ri < nr && rb.njobs < MAX_JOBS; ++ri)
+            rb.jobs[rb.njobs++] = h->pend_red[ri];
+        TailBatch tb{};
+        for (; ti < nt && tb.njobs < MAX_JOBS; ++ti)
+            tb.jobs[tb.njobs++] = ti < np ? h->pend_tail[ti] : extra[ti - np];
+        HIPCHK(h, launch_post(rb, tb, h->stream));
+    }
+    h->pend_red.clear();
+    h->pend_tail.clear();
+    return PSDC_OK;
+}
+
 // make room for absolute indices [base, new_end) in the current buffer
 int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
 {
     const size_t need = (size_t)(new_end - s.buf.base);
     if (need <= s.buf.cap)
         return PSDC_OK;
+    {
+        int rc = launch_deferred(h, {}); // a carried tail may still be on its way into this buffer
+        if (rc)
+            return rc;
+    }
     const size_t min_cap = (size_t)4 * (h->n + HBF_HALO) + 64;
     size_t cap = std::max(need + need / 2, min_cap);
     float *np[2] = {nullptr, nullptr};
@@ -237,6 +392,9 @@ int ensure_partial(psdc_handle *h, size_t floats)
     if (floats <= h->partial_cap)
         return PSDC_OK;
     if (h->d_partial) {
+        int rc = launch_deferred(h, {}); // the last round's partials are still to be folded
+        if (rc)
+            return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipFree(h->d_partial));
         h->d_partial = nullptr;
@@ -280,8 +438,9 @@ int collect_profile(psdc_handle *h)
 // segments in its stream buffer is issued, all stages in the SAME launches.
 // The decimator output of this round becomes visible to the next stage in the
 // next round (stage k+1 lags one round behind stage k), so a steady-state round
-// costs a seam copy, one fused launch and one post launch whatever the depth
-// (plus the generic welch / decimator kernels when something does not fit a pair).
+// costs two launches whatever the depth: a post launch (the seam copy of this round with the
+// deferred epilogue of the last one) and the fused launch (plus the generic welch / decimator
+// kernels when something does not fit a pair).
 // `all`: issue odd segments of decimated stages too (read-outs); the ingest path
 // leaves them for their partner.  *did_work tells whether anything was issued;
 // read-outs call rounds until idle.
@@ -315,14 +474,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             seams.push_back({c.span.d_x, s0.buf.p[s0.buf.cur] + (c.span.first - s0.buf.base), (int)cp});
             s0.buf.end = c.span.first + cp;
         }
-        for (size_t i = 0; i < seams.size();) {
-            RedBatch none{};
-            none.n = (int)h->n;
-            TailBatch tb{};
-            for (; i < seams.size() && tb.njobs < MAX_JOBS; ++i)
-                tb.jobs[tb.njobs++] = seams[i];
-            HIPCHK(h, launch_post(none, tb, h->stream));
-        }
+        int rc = launch_deferred(h, seams); // with the last round's epilogue
+        if (rc)
+            return rc;
     }
 
     // collect the work of this round from the totals as they stand now
@@ -687,17 +841,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             s.buf.end = s.total;
         }
     }
-    // epilogue launches: fold the partials and carry the tails together
-    for (size_t ri = 0, ti = 0; ri < rjobs.size() || ti < tjobs.size();) {
-        RedBatch rb{};
-        rb.n = (int)h->n;
-        for (; ri < rjobs.size() && rb.njobs < MAX_JOBS; ++ri)
-            rb.jobs[rb.njobs++] = rjobs[ri];
-        TailBatch tb{};
-        for (; ti < tjobs.size() && tb.njobs < MAX_JOBS; ++ti)
-            tb.jobs[tb.njobs++] = tjobs[ti];
-        HIPCHK(h, launch_post(rb, tb, h->stream));
-    }
+    // epilogue (fold the partials, carry the tails): deferred to the next launch_deferred()
+    h->pend_red = std::move(rjobs);
+    h->pend_tail = std::move(tjobs);
     for (auto &c : h->ch) {
         c.has_span = false;
         c.submitted = false;
@@ -1043,10 +1189,14 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_pool);
     if (h->h_read)
         (void)hipHostFree(h->h_read);
-    if (h->d_frames)
-        (void)hipFree(h->d_frames);
-    if (h->h_frames)
-        (void)hipHostFree(h->h_frames);
+    for (int i = 0; i < 2; ++i) {
+        if (h->d_frames[i])
+            (void)hipFree(h->d_frames[i]);
+        if (h->h_frames[i])
+            (void)hipHostFree(h->h_frames[i]);
+        if (h->frames_ev[i])
+            (void)hipEventDestroy(h->frames_ev[i]);
+    }
     if (h->d_win)
         (void)hipFree(h->d_win);
     if (h->d_tw)
@@ -1066,6 +1216,9 @@ int psdc_reset(psdc_handle *h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->pend_red.clear(); // the state they would update is discarded
+    h->pend_tail.clear();
+    h->idle = true;
     for (auto &c : h->ch) {
         for (auto &s : c.st) {
             int rc = free_stage(h, s);
@@ -1163,7 +1316,7 @@ int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
     h->idle = false;
     while (len > 0) {
         const size_t take = std::min(len, h->quantum - c.fill);
-        memcpy(c.stage_host[c.cur_stage] + c.fill, x, sizeof(float) * take);
+        CopyPool::get().copy(c.stage_host[c.cur_stage] + c.fill, x, sizeof(float) * take);
         c.fill += take;
         x += take;
         len -= take;
@@ -1292,50 +1445,71 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
             if (rc)
                 return rc;
         }
-        const size_t bytes = good * frame_size;
-        if (bytes > h->frames_cap) {
+        // The frames go up in pieces of ~16 MiB through two pinned buffers: while one piece is on
+        // the link the host copies the next (several threads), and every piece is decoded and
+        // cascaded as soon as it has landed.
+        const size_t piece_frames = std::max<size_t>(1, ((size_t)16 << 20) / frame_size);
+        const size_t piece_bytes = piece_frames * frame_size;
+        if (piece_bytes > h->frames_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (h->d_frames)
-                HIPCHK(h, hipFree(h->d_frames));
-            if (h->h_frames)
-                HIPCHK(h, hipHostFree(h->h_frames));
-            h->d_frames = nullptr;
-            h->h_frames = nullptr;
-            HIPCHK(h, hipMalloc(&h->d_frames, bytes + bytes / 2));
-            HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_frames), bytes + bytes / 2,
-                                    hipHostMallocDefault));
-            h->frames_cap = bytes + bytes / 2;
-        } else {
-            HIPCHK(h, hipStreamSynchronize(h->stream)); // pinned bounce buffer is reused
-        }
-        memcpy(h->h_frames, frames, bytes);
-        HIPCHK(h, hipMemcpyAsync(h->d_frames, h->h_frames, bytes, hipMemcpyHostToDevice, h->stream));
-        const size_t per_ch = good * (size_t)batches * 8;
-        float *dst[4];
-        for (int ci = 0; ci < 4; ++ci) {
-            Channel &c = h->ch[ci];
-            if (c.st.empty()) {
-                rc = add_stage(h, c);
-                if (rc)
-                    return rc;
+            for (int i = 0; i < 2; ++i) {
+                if (h->d_frames[i])
+                    HIPCHK(h, hipFree(h->d_frames[i]));
+                if (h->h_frames[i])
+                    HIPCHK(h, hipHostFree(h->h_frames[i]));
+                h->d_frames[i] = nullptr;
+                h->h_frames[i] = nullptr;
+                HIPCHK(h, hipMalloc(&h->d_frames[i], piece_bytes));
+                HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_frames[i]), piece_bytes,
+                                        hipHostMallocDefault));
+                if (!h->frames_ev[i])
+                    HIPCHK(h, hipEventCreateWithFlags(&h->frames_ev[i], hipEventDisableTiming));
+                h->frames_ev_pending[i] = false;
             }
-            StageState &s0 = c.st[0];
-            rc = ensure_room(h, s0, s0.total + per_ch);
-            if (rc)
-                return rc;
-            dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
+            h->frames_cap = piece_bytes;
         }
         h->idle = false;
-        HIPCHK(h, launch_adcdac(h->d_frames, frame_size, good, batches, dst[0], dst[1], dst[2], dst[3],
-                                h->stream));
-        for (int ci = 0; ci < 4; ++ci) {
-            h->ch[ci].st[0].total += per_ch;
-            h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
-            h->ch[ci].submitted = true;
+        for (size_t f0 = 0; f0 < good; f0 += piece_frames) {
+            const size_t cnt = std::min(piece_frames, good - f0);
+            const size_t bytes = cnt * frame_size;
+            const int b = h->frames_cur;
+            if (h->frames_ev_pending[b]) { // the bounce buffer's last upload must have left it
+                HIPCHK(h, hipEventSynchronize(h->frames_ev[b]));
+                h->frames_ev_pending[b] = false;
+            }
+            CopyPool::get().copy(h->h_frames[b], frames + f0 * frame_size, bytes);
+            HIPCHK(h, hipMemcpyAsync(h->d_frames[b], h->h_frames[b], bytes, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipEventRecord(h->frames_ev[b], h->stream));
+            h->frames_ev_pending[b] = true;
+            h->frames_cur = b ^ 1;
+            const size_t per_ch = cnt * (size_t)batches * 8;
+            float *dst[4];
+            for (int ci = 0; ci < 4; ++ci) {
+                Channel &c = h->ch[ci];
+                if (c.st.empty()) {
+                    rc = add_stage(h, c);
+                    if (rc)
+                        return rc;
+                }
+                StageState &s0 = c.st[0];
+                rc = ensure_room(h, s0, s0.total + per_ch);
+                if (rc)
+                    return rc;
+                dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
+            }
+            // (the device image d_frames[b] is next written two pieces later, behind this kernel
+            // in the stream)
+            HIPCHK(h, launch_adcdac(h->d_frames[b], frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3],
+                                    h->stream));
+            for (int ci = 0; ci < 4; ++ci) {
+                h->ch[ci].st[0].total += per_ch;
+                h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
+                h->ch[ci].submitted = true;
+            }
+            rc = advance(h);
+            if (rc)
+                return rc;
         }
-        rc = advance(h);
-        if (rc)
-            return rc;
     }
     if (n_ok)
         *n_ok = good;
