@@ -379,6 +379,38 @@ def test_adcdac_frames(pkg, ora, gpu_required):
     g.close()
 
 
+def test_adcdac_frames_pipelined(pkg, ora, gpu_required):
+    """One call holding more than two 16 MiB pieces of frames: the double-buffered, multi-threaded
+    upload must deliver every frame once and in order (checked on all four traces)."""
+    n, batches, nframes = 1024, 22, 26000
+    rng = np.random.default_rng(10)
+    raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8)) * 3000), -32768, 32767).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, batches, seq0=7)
+    assert len(data) > 2 * (16 << 20)
+    g = pkg.PsdCascadeBank(n, 4)
+    assert g.process_adcdac_frames(data, fs) == nframes
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    traces = [[] for _ in range(4)]
+    for f in range(nframes):
+        st, seq, nb, tr = ora.adcdac_decode(data[f * fs:(f + 1) * fs])
+        assert st == 0 and nb == batches
+        for c in range(4):
+            traces[c].append(tr[c])
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [np.concatenate(traces[c])], n, channel=c, what=pkg.ADCDAC_TRACES[c])
+    g.close()
+
+
+def test_host_fed_large_call(pkg, ora, gpu_required):
+    """psdc_process with several staging quanta in one call (threaded copies into the pinned buffers)."""
+    n, total = 1024, (1 << 23) + 3 * 4099
+    x = pkg.noise_host(total, seed=77)
+    g = pkg.PsdCascade(n)
+    g.process(x)
+    check_against_oracle(pkg, ora, g._b, [x], n, what="host-fed large call")
+    g.close()
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch
