@@ -86,6 +86,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
     __shared__ float4 s_win[N / 4]; // window: float4 piece m of team-lane tl at [TEAM m + tl]
     __shared__ float s_hist[TEAMS * G::HIST];
 
+#ifdef PSDK_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int tm = lane / TEAM, tl = lane % TEAM; // team within the wavefront, lane within the team
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
     const bool stamp_on = wb == 0 && run >= 8 && tid < 64; // first workgroup of a long-run job
     unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    st[9] = tprev - t_entry; // tables + window + job lookup
 #endif
 
     // this team's run: pairs [p0, p0 + nrun) of the job (the job's last teams get fewer or none)
@@ -197,6 +201,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
         wave_sync();
     }
 
+    // between pairs the carried state (element tl + TEAM r of the 80) lives in registers when that
+    // takes few of them (N >= 512), else in the LDS side buffer
+    constexpr bool HREG = HR <= 3;
+    float hreg[HR];
+#pragma unroll
+    for (int r = 0; r < HR; ++r)
+        hreg[r] = (HREG && tl + TEAM * r < G::HIST) ? hs[tl + TEAM * r] : 0.0f;
+    PSDK_STAMP(10); // first loads issued + warm-up
     // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
     // nl = lower half of chunk p + 1.  Once lo/up have been windowed into the FFT registers
     // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
 #pragma unroll
         for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
-                sf[h_pack[r] & 0xFFFFu] = hs[tl + TEAM * r];
+                sf[h_pack[r] & 0xFFFFu] = HREG ? hreg[r] : hs[tl + TEAM * r];
         // samples -> polyphase arrays as single floats: pairs of them leave as ds_write2_b32 from
         // whatever registers the loads delivered them to (an 8-byte store of {x, z} would need the
         // two in adjacent registers, i.e. moves right behind the loads)
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
 #pragma unroll
         for (int r = 0; r < HR; ++r) // tails of A and B -> carried state
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
-                hs[tl + TEAM * r] = sf[h_pack[r] >> 16];
+                (HREG ? hreg[r] : hs[tl + TEAM * r]) = sf[h_pack[r] >> 16];
         wave_sync(); // the frame is reused by the FFT
         PSDK_STAMP(4);
 
@@ -379,13 +391,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
         }
     }
 
-#ifdef PSDK_STAMPS
-    if (stamp_on && tid == 0) {
-        for (int k = 0; k < 12; ++k)
-            g_stamps[k] = st[k];
-        g_stamps[12] = (unsigned long long)run;
-    }
-#endif
+    PSDK_STAMP(0);
     // combine the teams; partial in natural bin order
 #pragma unroll
     for (int s = 0; s < 16; ++s)
@@ -400,6 +406,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             acc += all[g * G::SCR + k];
         out[k] = acc;
     }
+#ifdef PSDK_STAMPS
+    PSDK_STAMP(11); // team combine + partial store
+    if (stamp_on && tid == 0) {
+        for (int k = 0; k < 12; ++k)
+            g_stamps[k] = st[k];
+        g_stamps[12] = (unsigned long long)nrun;
+    }
+#endif
 }
 
 bool fused_supported(int n)

@@ -32,4 +32,5 @@ tot = sum(out[k] for k in range(9))
 print(f"N={n} run={run} pairs/team; shader cycles per pair (s_memtime)")
 for k, nm in enumerate(names):
     print(f"  {nm:28s} {out[k] / max(run, 1):9.1f}  {100.0 * out[k] / max(tot, 1):5.1f}%")
-print(f"  total {tot / max(run, 1):.1f} ticks/pair")
+print(f"  total {tot / max(run, 1):.1f} cycles/pair, {tot} in the loop")
+print(f"  once per run: tables/window {out[9]}, first loads + warm-up {out[10]}, combine + store {out[11]} cycles")
