@@ -448,7 +448,7 @@ int fused_max_blocks(int n)
     case 16384:
         return 256; // 1024 threads, 139 KB
     default:
-        return 512; // 8 wavefronts, <= 80 KB: two per CU
+        return 256 * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES); // 8 wavefronts, <= 80 KB: two per CU
     }
 }
 

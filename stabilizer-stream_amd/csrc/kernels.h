@@ -10,7 +10,10 @@
 
 namespace psdk {
 
-constexpr int MAX_JOBS = 32;
+#ifndef PSDK_MAX_JOBS
+#define PSDK_MAX_JOBS 128
+#endif
+constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
 
 // One span of consecutive segments of one (channel, stage) stream.
 struct SegJob {
