@@ -222,33 +222,66 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
         for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
                 sf[h_pack[r] & 0xFFFFu] = HREG ? hreg[r] : hs[tl + TEAM * r];
-        // samples -> polyphase arrays as single floats: pairs of them leave as ds_write2_b32 from
-        // whatever registers the loads delivered them to (an 8-byte store of {x, z} would need the
-        // two in adjacent registers, i.e. moves right behind the loads)
-        auto split = [&](int h, const float4 &x) {
-            sf[G::XE + h] = x.x;
-            sf[G::XE + h + 1] = x.z;
-            sf[G::XO + h] = x.y;
-            sf[G::XO + h + 1] = x.w;
-        };
-        if (tl >= TEAM - 3) // the 12 samples before the new ones (end of chunk p's lower half)
-            split(2 * (tl - (TEAM - 3)), lo[1]);
-        {
-            const int h = G::HX / 2 + 2 * tl;
-            split(h, up[0]);
-            split(h + N / 8, up[1]);
-            split(h + N / 4, nl[0]);
-            split(h + 3 * N / 8, nl[1]);
-        }
-        wave_sync();
-        PSDK_STAMP(1);
+        if constexpr (TEAM == 64) {
+            // Stage A straight from the registers the loads filled: lane tl holds samples
+            // 4tl..4tl+3 of each 256-sample piece = (xe[2tl], xo[2tl], xe[2tl+1], xo[2tl+1]); the
+            // outputs (2tl, 2tl+1) of a piece need the three lanes below, fetched with DPP
+            // wavefront shifts (lane 0.. of a piece continue into the top lanes of the piece before).
+            // No LDS traffic for the input side of the stage.
+            const float4 *pc[5] = {&lo[1], &up[0], &up[1], &nl[0], &nl[1]};
+            float p1y = dpp_shr1(0.0f, pc[0]->y), p1w = dpp_shr1(0.0f, pc[0]->w); // only lane 63 is used
+            float p2w = dpp_shr1(0.0f, p1w);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, (2u, 2u+1) -> AE/AO[11 + u]
-            const int u = tl + TEAM * r;
-            float y0, y1;
-            hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
-            sf[G::AE + 11 + u] = y0;
-            sf[G::AO + 11 + u] = y1;
+            for (int r = 0; r < 4; ++r) {
+                const float4 &pv = *pc[r], &cu = *pc[r + 1];
+                const float s1x = dpp_shr1(dpp_ror1(pv.x), cu.x), s1y = dpp_shr1(dpp_ror1(pv.y), cu.y);
+                const float s1z = dpp_shr1(dpp_ror1(pv.z), cu.z), s1w = dpp_shr1(dpp_ror1(pv.w), cu.w);
+                const float s2y = dpp_shr1(dpp_ror1(p1y), s1y), s2w = dpp_shr1(dpp_ror1(p1w), s1w);
+                const float s3w = dpp_shr1(dpp_ror1(p2w), s2w);
+                // out j = xe[j-2] + t0 (xo[j-5] + xo[j]) + t1 (xo[j-4] + xo[j-1]) + t2 (xo[j-3] + xo[j-2])
+                float a0 = 0.0f, a1 = 0.0f;
+                a0 += (s3w + cu.y) * ta[0];
+                a1 += (s2y + cu.w) * ta[0];
+                a0 += (s2y + s1w) * ta[1];
+                a1 += (s2w + cu.y) * ta[1];
+                a0 += (s2w + s1y) * ta[2];
+                a1 += (s1y + s1w) * ta[2];
+                const int u = tl + TEAM * r;
+                sf[G::AE + 11 + u] = s1x + a0;
+                sf[G::AO + 11 + u] = s1z + a1;
+                p1y = s1y;
+                p1w = s1w;
+                p2w = s2w;
+            }
+        } else {
+            // samples -> polyphase arrays as single floats: pairs of them leave as ds_write2_b32 from
+            // whatever registers the loads delivered them to (an 8-byte store of {x, z} would need the
+            // two in adjacent registers, i.e. moves right behind the loads)
+            auto split = [&](int h, const float4 &x) {
+                sf[G::XE + h] = x.x;
+                sf[G::XE + h + 1] = x.z;
+                sf[G::XO + h] = x.y;
+                sf[G::XO + h + 1] = x.w;
+            };
+            if (tl >= TEAM - 3) // the 12 samples before the new ones (end of chunk p's lower half)
+                split(2 * (tl - (TEAM - 3)), lo[1]);
+            {
+                const int h = G::HX / 2 + 2 * tl;
+                split(h, up[0]);
+                split(h + N / 8, up[1]);
+                split(h + N / 4, nl[0]);
+                split(h + 3 * N / 8, nl[1]);
+            }
+            wave_sync();
+            PSDK_STAMP(1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, (2u, 2u+1) -> AE/AO[11 + u]
+                const int u = tl + TEAM * r;
+                float y0, y1;
+                hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
+                sf[G::AE + 11 + u] = y0;
+                sf[G::AO + 11 + u] = y1;
+            }
         }
         wave_sync();
         PSDK_STAMP(2);
@@ -359,6 +392,26 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             lo[1] = src[N / 4 + TEAM];
         }
         PSDK_STAMP(5);
+#ifdef PSDK_EXTRA_VALU // sensitivity probe: dummy VALU work per pair (never defined in the shipped build)
+        {
+            float d[8] = {v[0].re, v[0].im, v[1].re, v[1].im, v[2].re, v[2].im, v[3].re, v[3].im};
+#pragma unroll
+            for (int e = 0; e < PSDK_EXTRA_VALU; ++e) // eight independent chains
+                asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(d[e & 7]) : "v"(v[4].re));
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                asm volatile("" ::"v"(d[e]));
+        }
+#endif
+#ifdef PSDK_EXTRA_LDS // sensitivity probe: dummy 8-byte LDS reads per pair
+        {
+            float d = 0.0f;
+#pragma unroll
+            for (int e = 0; e < PSDK_EXTRA_LDS; ++e)
+                d += lds_ld(frame + 17 * tl + (e & 15)).re;
+            asm volatile("" ::"v"(d));
+        }
+#endif
         T::pass0(tl, v, s_tw0);
         T::store0(tl, v, frame);
         wave_sync();

@@ -66,6 +66,20 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// DPP wavefront shifts (gfx9 family): dpp_shr1(fill, v)[l] = v[l - 1] for l >= 1 and fill[0] for
+// l = 0; dpp_ror1(v)[0] = v[63].  Together: a shift that continues into another register's top lane
+// (semantics checked on the device by tools/probes/dpp_shift.cpp).
+__device__ __forceinline__ float dpp_shr1(float fill, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill),
+                                                                 __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_ror1(float v)
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+}
+
 struct f2 {
     float x, y;
 };
