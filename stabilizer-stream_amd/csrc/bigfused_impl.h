@@ -67,6 +67,7 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
     const int p0 = wb * run;
     const int p1 = min(npairs, p0 + run);
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tl;
+    const float4 *safe = cp; // look-ahead target once nothing is left to look ahead to
     float4 ga[2], gb[2], gc[2];
     ga[0] = cp[0];
     ga[1] = cp[TEAM];
@@ -111,21 +112,22 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
         // ---- decimator ------------------------------------------------------------------
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
             sf[h_pack & 0xFFFFu] = hs[tl];
-        if (tl >= TEAM - 3) {
-            const int h = 2 * (tl - (TEAM - 3));
-            *reinterpret_cast<f2 *>(sf + G::XE + h) = {lo[1].x, lo[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h) = {lo[1].y, lo[1].w};
-        }
+        // samples -> polyphase arrays as single floats (ds_write2_b32 from the registers the loads
+        // filled; an 8-byte store of {x, z} would cost moves right behind the loads)
+        auto split = [&](int h, const float4 &x) {
+            sf[G::XE + h] = x.x;
+            sf[G::XE + h + 1] = x.z;
+            sf[G::XO + h] = x.y;
+            sf[G::XO + h + 1] = x.w;
+        };
+        if (tl >= TEAM - 3)
+            split(2 * (tl - (TEAM - 3)), lo[1]);
         {
             const int h = G::HX / 2 + 2 * tl;
-            *reinterpret_cast<f2 *>(sf + G::XE + h) = {up[0].x, up[0].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h) = {up[0].y, up[0].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 8) = {up[1].x, up[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 8) = {up[1].y, up[1].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + N / 4) = {nl[0].x, nl[0].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + N / 4) = {nl[0].y, nl[0].w};
-            *reinterpret_cast<f2 *>(sf + G::XE + h + 3 * N / 8) = {nl[1].x, nl[1].z};
-            *reinterpret_cast<f2 *>(sf + G::XO + h + 3 * N / 8) = {nl[1].y, nl[1].w};
+            split(h, up[0]);
+            split(h + N / 8, up[1]);
+            split(h + N / 4, nl[0]);
+            split(h + 3 * N / 8, nl[1]);
         }
         __syncthreads();
 #pragma unroll
@@ -258,11 +260,15 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
             put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
         }
-        if (more) { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo (in flight during the FFT)
-            up[0] = cnext[2 * TEAM];
-            up[1] = cnext[3 * TEAM];
-            lo[0] = cnext[N / 4];
-            lo[1] = cnext[N / 4 + TEAM];
+        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT; issued
+          // unconditionally (after the last pair: re-reads of pieces read before, unused) so that
+          // the compiler does not wait for them at the end of a branch
+            const float4 *src = more ? cnext : safe;
+            safe = src;
+            up[0] = src[2 * TEAM];
+            up[1] = src[3 * TEAM];
+            lo[0] = src[N / 4];
+            lo[1] = src[N / 4 + TEAM];
         }
         T::pass0(tl, v, tw0g);
         T::store0(tl, v, frame);
