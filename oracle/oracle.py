@@ -60,6 +60,7 @@ def _declare(L):
         f("ora_cascade_set_detrend", i32, [vp, i32])
         f("ora_cascade_process", i32, [vp, fp, sz])
         f("ora_cascade_num_stages", i32, [vp])
+        f("ora_cascade_ref_would_panic", i32, [vp])
         f("ora_cascade_stage_info", i32, [vp, i32, C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64), C.POINTER(u64)])
         f("ora_cascade_stage_spectrum", i32, [vp, i32, rp])
@@ -135,6 +136,12 @@ class PsdCascade:
     @property
     def num_stages(self):
         return self._f("ora_cascade_num_stages")(self.h)
+
+    @property
+    def ref_would_panic(self):
+        """True once a feed pattern occurred on which the reference's [f32; N] ping-pong buffers
+        overflow (src/psd.rs:253 with :457): a short first call, then a full 8N chunk."""
+        return bool(self._f("ora_cascade_ref_would_panic")(self.h))
 
     def stage_info(self, k):
         c, a, p, q = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()

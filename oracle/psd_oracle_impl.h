@@ -279,6 +279,7 @@ typedef struct {
     int detrend;            /* :132 */
     uint32_t avg;           /* :133 */
     REAL *c;                /* scratch complex frame */
+    int wrote_past_n;       /* a write went past y[N): the cascade's [f32; N] would have panicked */
 } SFX(ora_psd);
 
 static int SFX(psd_init)(SFX(ora_psd) * s, const SFX(ora_fft) * fft, const SFX(ora_window_t) * win)
@@ -296,6 +297,7 @@ static int SFX(psd_init)(SFX(ora_psd) * s, const SFX(ora_fft) * fft, const SFX(o
         return -1;
     s->idx = 0;
     s->count = 0;
+    s->wrote_past_n = 0;
     s->fft = fft;
     s->win = win;
     s->detrend = 0;
@@ -364,6 +366,8 @@ static long SFX(psd_process)(SFX(ora_psd) * s, const REAL *x, size_t xlen, REAL 
         if ((n - start) % 8 != 0)
             return -1; /* assert!(xr.is_empty()) :247 */
         const int nb = (n - start) / 8;
+        if (nout + (size_t)nb > (size_t)n)
+            s->wrote_past_n = 1; /* y[n..][..xb.len()] with y: [f32; N] would panic (:253, :457) */
         SFX(hbf8_block)(&s->hbf, s->buf + start, nb, y + nout);
         /* drain :255-260 */
         int skip = s->drain < nb ? s->drain : nb;
@@ -401,6 +405,14 @@ typedef struct SFX(ora_cascade)
     int n_stages;
     SFX(ora_psd) stages[ORA_MAX_STAGES];
     REAL *a0, *a1, *xin; /* ping-pong + converted input chunk */
+    /* Set when a stage wrote past N items of its output buffer.  The reference's ping-pong buffers
+     * are [f32; N] (src/psd.rs:457-458) although PsdStage::process asks for x.len()/8 + N/8
+     * (SURVEY.md row A4): when a call completes 16 segments INCLUDING the stream's first one (some
+     * samples were buffered by an earlier short call, then a full 8N chunk arrives) stage 0 emits
+     * N + N/16 - 35 items and `&mut y[n..][..xb.len()]` (src/psd.rs:253) panics.  The oracle sizes
+     * its buffers as the contract asks and keeps going, so that chunk invariance can be tested on
+     * such feeds too; this flag says the reference would have panicked. */
+    int ref_would_panic;
 } SFX(ora_cascade);
 
 static uint32_t SFX(stage_avg)(const SFX(ora_cascade) * c, int i)
@@ -424,8 +436,8 @@ SFX(ora_cascade) * SFX(ora_cascade_new)(int n, int window_kind)
     c->detrend = 0;             /* :418 */
     c->avg_limit = UINT32_MAX;  /* :369-375 */
     c->avg_count = UINT32_MAX;
-    c->a0 = (REAL *)calloc((size_t)n, sizeof(REAL));
-    c->a1 = (REAL *)calloc((size_t)n, sizeof(REAL));
+    c->a0 = (REAL *)calloc((size_t)n + (size_t)n / 8 + 8, sizeof(REAL)); /* x.len()/8 + N/8 */
+    c->a1 = (REAL *)calloc((size_t)n + (size_t)n / 8 + 8, sizeof(REAL));
     c->xin = (REAL *)calloc((size_t)n * 8, sizeof(REAL));
     return c;
 }
@@ -496,6 +508,8 @@ int SFX(ora_cascade_process)(SFX(ora_cascade) * c, const float *x, size_t len)
             long nn = SFX(psd_process)(s, xp, xl, y);
             if (nn < 0)
                 return -1;
+            if (s->wrote_past_n)
+                c->ref_would_panic = 1;
             REAL *t = z; /* swap :463 */
             z = y;
             y = t;
@@ -510,6 +524,9 @@ int SFX(ora_cascade_process)(SFX(ora_cascade) * c, const float *x, size_t len)
 }
 
 int SFX(ora_cascade_num_stages)(const SFX(ora_cascade) * c) { return c->n_stages; }
+
+/* 1 if some call so far would have made the reference panic at src/psd.rs:253 (see ref_would_panic) */
+int SFX(ora_cascade_ref_would_panic)(const SFX(ora_cascade) * c) { return c->ref_would_panic; }
 
 typedef struct {
     uint32_t count;

@@ -1052,6 +1052,22 @@ int psdc_abi_version(void) { return PSDC_ABI_VERSION; }
 
 const char *psdc_last_error(const psdc_handle *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
+#ifdef PSDK_SEGV_TRACE // debugging aid (tools/build_variants.sh ... "-g -DPSDK_SEGV_TRACE"), never in the shipped build
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void psdk_segv(int sig)
+{
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(128 + sig);
+}
+struct PsdkSegvInstall {
+    PsdkSegvInstall() { signal(SIGSEGV, psdk_segv); }
+} g_psdk_segv_install;
+#endif
+
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device)
 {
     WindowConsts wc{};

@@ -3,6 +3,8 @@
 Reference behaviour under test: src/psd.rs:196-269 (segment loop), :75-113 (detrend),
 :218-233 (EWMA), :246-260 (decimate + drain), :456-468 (cascade), :479-543 (stitch).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -411,6 +413,25 @@ def test_host_fed_large_call(pkg, ora, gpu_required):
     g.close()
 
 
+def test_feed_the_reference_panics_on(pkg, ora, gpu_required):
+    """Short first call, then a full 8N chunk: the reference's [f32; N] stage buffers overflow
+    (src/psd.rs:253/:457, see tests/test_oracle_reference.py::test_short_first_call_then_full_chunk).
+    The library's contract is the stream, not the chunking: it must match the oracle's stream
+    semantics here as well."""
+    n = 1024
+    x = pkg.noise_host(900 + 8 * n + 70000, seed=41)
+    chunks = [x[:900], x[900:900 + 8 * n], x[900 + 8 * n:]]
+    g = pkg.PsdCascadeBank(n, 1)
+    for c in chunks:
+        g.process(0, c)
+    ref_flag = ora.PsdCascade(n, "f64")
+    for c in chunks:
+        ref_flag.process(c)
+    assert ref_flag.ref_would_panic
+    check_against_oracle(pkg, ora, g, chunks, n, what="short first call + 8N chunk")
+    g.close()
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch
@@ -449,7 +470,8 @@ def test_full_size_properties(pkg, gpu_required):
         h.close()
 
 
-@pytest.mark.parametrize("n,seed", [(256, 1), (512, 2), (1024, 3), (1024, 4), (2048, 5), (64, 6)])
+@pytest.mark.parametrize("n,seed", [(256, 1), (512, 2), (1024, 3), (1024, 4), (2048, 5), (64, 6), (1024, 7),
+                                    (1024, 8), (512, 9), (4096, 10), (256, 11), (1024, 12)])
 def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     """Seeded random mix of everything the boundary allows: host and in-place device feeding with odd
     lengths and alignments, tiny and large spans, mid-stream read-outs, detrend / averaging changes,
@@ -493,7 +515,10 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
         m = int(rng.choice([rng.integers(1, 50), rng.integers(1, 6 * n), rng.integers(6 * n, 40 * n)]))
         m = min(m, total - pos[c])
         a, b = pos[c], pos[c] + m
-        if rng.random() < 0.5:
+        host = rng.random() < 0.5
+        if os.environ.get("PSD_STRESS_TRACE"):
+            print(f"feed ch{c} {'host' if host else 'dev'} [{a},{b})", flush=True)
+        if host:
             g.process(c, xs[c][a:b])
         else:
             g.process_device(c, xd[c].data_ptr() + 4 * a, m)

@@ -184,3 +184,30 @@ def test_adcdac_decode(ora):
     assert ora.adcdac_decode(frame[:2] + b"\x09" + frame[3:])[0] == -2  # UnknownFormat
     assert ora.adcdac_decode(frame[:-3])[0] == -3  # PayloadSize
     assert ora.adcdac_decode(frame[:3] + b"\x04" + frame[4:])[0] == -4  # batches mismatch panics
+
+
+def test_short_first_call_then_full_chunk(ora):
+    """A feed the reference cannot take: its cascade hands every stage a [f32; N] output buffer
+    (src/psd.rs:457-458) although PsdStage::process may emit x.len()/8 + N/8 items -- after a short
+    first call (< N samples buffered, no segment yet) a full 8N chunk completes 16 segments INCLUDING
+    the stream's first, N + N/16 - 35 items, and `&mut y[n..][..xb.len()]` (:253) panics.  The
+    oracle sizes its buffers as the contract asks, flags the condition and keeps the stream
+    semantics (same result as an aligned feed), which is what the GPU path is held to."""
+    n = 1024
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(900 + 8 * n + 3000).astype(np.float32)
+    a = ora.PsdCascade(n, "f64")
+    a.process(x[:900])
+    assert not a.ref_would_panic
+    a.process(x[900:900 + 8 * n])
+    assert a.ref_would_panic
+    a.process(x[900 + 8 * n:])
+    b = ora.PsdCascade(n, "f64")
+    for i in range(0, x.size, 512):
+        b.process(x[i:i + 512])
+    assert not b.ref_would_panic
+    assert a.num_stages == b.num_stages
+    for k in range(a.num_stages):
+        assert a.stage_info(k) == b.stage_info(k)
+        np.testing.assert_array_equal(a.stage_spectrum(k), b.stage_spectrum(k))
+        np.testing.assert_array_equal(a.stage_buf(k), b.stage_buf(k))
