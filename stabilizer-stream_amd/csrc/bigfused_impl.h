@@ -158,7 +158,8 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             hs[tl] = sf[h_pack >> 16];
 
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
-        float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
+        float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
+        slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
         if constexpr (DETREND == 1 || DETREND == 3) { // pivot: the segments' midpoint samples
             if (tl == 0) {
                 s_red[0] = up[0].x;
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
         } else if constexpr (DETREND == 2) {
             oa = s_red[0];
             ob = s_red[1];
-            sa = (s_red[2] - oa) / (float)(N - 1);
-            sb = (s_red[3] - ob) / (float)(N - 1);
+            sa = span_slope(oa, s_red[2], N);
+            sb = span_slope(ob, s_red[3], N);
         }
         if constexpr (DETREND == 3) { // Mean about the pivot
             auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
                     xb -= ob;
                 } else if constexpr (DETREND == 2) {
                     const float n = nf + (float)nofs;
-                    xa = fmaf(-n, sa, xa - oa);
-                    xb = fmaf(-n, sb, xb - ob);
+                    xa = fmaf(-n, sa.lo, fmaf(-n, sa.hi, xa - oa));
+                    xb = fmaf(-n, sb.lo, fmaf(-n, sb.hi, xb - ob));
                 } else if constexpr (DETREND == 3) {
                     xa = (xa - oa) - ma;
                     xb = (xb - ob) - mb;

@@ -40,6 +40,31 @@ PSDK_HD cf lds_ld(const cf *p)
 #endif
 }
 
+// Span detrend (src/psd.rs:94-102): slope (x[N-1] - x[0]) / (N - 1) as an unevaluated sum hi + lo.
+// A slope rounded to f32 leaves a ramp error of up to D 2^-24 at the end of the segment, coherent over
+// the segment: in the lowest bins that is ~1e-5 of the power at N >= 8192 (D = the span, a few sigma).
+// The two-term slope follows the exact ramp to ~1e-14; the reference's own f32 ramp (sequential
+// offset += slope) does not, the f64 oracle does.
+struct slope2 {
+    float hi, lo;
+};
+PSDK_HD slope2 span_slope(float first, float last, int n)
+{
+    const float dh = last - first; // TwoSum of last + (-first): dh + dl is the exact difference
+    const float bp = dh - last;
+    const float dl = (last - (dh - bp)) + (-first - bp);
+    const float nm1 = (float)(n - 1);
+    slope2 s;
+    s.hi = dh / nm1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rem = __fmaf_rn(-s.hi, nm1, dh) + dl;
+#else
+    const float rem = (float)((double)dh - (double)s.hi * (double)nm1) + dl;
+#endif
+    s.lo = rem / nm1;
+    return s;
+}
+
 PSDK_HD cf cadd(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 PSDK_HD cf csub(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
 PSDK_HD cf cmul(cf a, cf b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }

@@ -313,16 +313,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
             // segment a = (lo, up), segment b = (up, nl).  The trend is removed as
             // (x - o) - (m + n s): o is a sample of the segment (exact difference), the remainder is
             // small, so a DC level far above the noise does not cost the result its low bits.
-            float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
+            float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
+            slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
             const int l0 = lane - tl; // first lane of this team
             if constexpr (DETREND == 1) { // Midpoint: x[N/2] (src/psd.rs:87-93)
                 oa = team_bcast<TEAM>(up[0].x, l0, 0);
                 ob = team_bcast<TEAM>(nl[0].x, l0, 0);
             } else if constexpr (DETREND == 2) { // Span (src/psd.rs:94-102), ramp as o + n s
                 oa = team_bcast<TEAM>(lo[0].x, l0, 0);
-                sa = (team_bcast<TEAM>(up[1].w, l0, TEAM - 1) - oa) / (float)(N - 1);
+                sa = span_slope(oa, team_bcast<TEAM>(up[1].w, l0, TEAM - 1), N);
                 ob = team_bcast<TEAM>(up[0].x, l0, 0);
-                sb = (team_bcast<TEAM>(nl[1].w, l0, TEAM - 1) - ob) / (float)(N - 1);
+                sb = span_slope(ob, team_bcast<TEAM>(nl[1].w, l0, TEAM - 1), N);
             } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109), summed about the midpoint sample
                 oa = team_bcast<TEAM>(up[0].x, l0, 0);
                 ob = team_bcast<TEAM>(nl[0].x, l0, 0);
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
                     xb -= ob;
                 } else if constexpr (DETREND == 2) {
                     const float n = nf + (float)nofs;
-                    xa = fmaf(-n, sa, xa - oa);
-                    xb = fmaf(-n, sb, xb - ob);
+                    xa = fmaf(-n, sa.lo, fmaf(-n, sa.hi, xa - oa));
+                    xb = fmaf(-n, sb.lo, fmaf(-n, sb.hi, xb - ob));
                 } else if constexpr (DETREND == 3) {
                     xa = (xa - oa) - ma;
                     xb = (xb - ob) - mb;

@@ -116,18 +116,19 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
 
         // Detrend (src/psd.rs:75-113) as (x - o) - (m + n s): o is a sample of the segment, so the
         // first difference is exact and a DC level far above the noise costs no low bits
-        float oa = 0.0f, ob = 0.0f, sa = 0.0f, sb = 0.0f, ma = 0.0f, mb = 0.0f;
+        float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
+        slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
         if (detrend == 1) { // Midpoint :87-93
             oa = act_a ? xa[N / 2] : 0.0f;
             ob = act_b ? xb[N / 2] : 0.0f;
         } else if (detrend == 2) { // Span :94-102 (ramp evaluated as o0 + n*slope)
             if (act_a) {
                 oa = xa[0];
-                sa = (xa[N - 1] - oa) / (float)(N - 1);
+                sa = span_slope(oa, xa[N - 1], N);
             }
             if (act_b) {
                 ob = xb[0];
-                sb = (xb[N - 1] - ob) / (float)(N - 1);
+                sb = span_slope(ob, xb[N - 1], N);
             }
         } else if (detrend == 3) { // Mean :103-109, summed about the midpoint sample (pivot)
             const float va = act_a ? xa[N / 2] : 0.0f, vb = act_b ? xb[N / 2] : 0.0f;
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 const float w = win[nidx];
                 float a = ra[s], b = rb[s];
                 if (detrend != 0) {
-                    a = fmaf(-(float)nidx, sa, a - oa) - ma;
-                    b = fmaf(-(float)nidx, sb, b - ob) - mb;
+                    a = fmaf(-(float)nidx, sa.lo, fmaf(-(float)nidx, sa.hi, a - oa)) - ma;
+                    b = fmaf(-(float)nidx, sb.lo, fmaf(-(float)nidx, sb.hi, b - ob)) - mb;
                 }
                 a *= w;
                 b *= w;

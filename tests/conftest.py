@@ -79,6 +79,28 @@ def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN)
     return float(np.max(err / np.maximum(np.abs(ref), 1e-300)))
 
 
+def assert_psd_close_anchored(got, ref, n, count, xmax, what=""):
+    """assert_psd_close for spectra taken under Midpoint / Span detrend (src/psd.rs:87-102), whose
+    offset is anchored on ONE sample of the segment.  A stage >= 1 stream is f32 (in the reference
+    too): the anchor sample carries a rounding error of up to ~1 ulp(|x|) against the f64 oracle's
+    stream, and that error is a coherent offset over the whole segment -- it lands in bins 0 and 1
+    with the window's weight (Hann: N/2 and N/4).  Per segment the power moves by up to
+    2 |X[k]| ulp W[k]; over `count` segments by 2 ulp W[k] sqrt(count * P[k]) at most.  All other
+    bins keep the plain tolerance."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    tol = RTOL * np.abs(ref) + ATOL_FRAC * np.mean(np.abs(ref)) + DYN * np.sqrt(np.abs(ref) * np.max(np.abs(ref)))
+    ulp = float(np.spacing(np.float32(xmax)))
+    for k, wk in ((0, n / 2.0), (1, n / 4.0)):
+        if k < ref.size:
+            tol[k] += 2.0 * ulp * wk * np.sqrt(max(1, count) * abs(ref[k])) + (ulp * wk) ** 2 * max(1, count)
+    err = np.abs(got - ref)
+    worst = int(np.argmax(err / tol))
+    assert np.all(err <= tol), (f"{what}: bin {worst} got {got[worst]:.9g} ref {ref[worst]:.9g} "
+                                f"err/tol {err[worst] / tol[worst]:.3g}")
+
+
 def test_signal(pkg, length, seed, tone=0.0, dc=0.0, f0=0.01234):
     """Unit-variance uniform noise (src/psd.rs:604-606) + optional tone and offset."""
     x = pkg.noise_host(length, seed)
