@@ -160,7 +160,7 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
         float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
         slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
-        if constexpr (DETREND == 1 || DETREND == 3) { // pivot: the segments' midpoint samples
+        if constexpr (DETREND == 1) { // the segments' midpoint samples
             if (tl == 0) {
                 s_red[0] = up[0].x;
                 s_red[1] = nl[0].x;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             }
         }
         __syncthreads(); // the frame is reused by the FFT; s_red published
-        if constexpr (DETREND == 1 || DETREND == 3) {
+        if constexpr (DETREND == 1) {
             oa = s_red[0];
             ob = s_red[1];
         } else if constexpr (DETREND == 2) {
@@ -185,27 +185,38 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             sa = span_slope(oa, s_red[2], N);
             sb = span_slope(ob, s_red[3], N);
         }
-        if constexpr (DETREND == 3) { // Mean about the pivot
+        if constexpr (DETREND == 3) { // Mean in two steps: o = f32 mean of the samples, m = mean of x - o
+            // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
+            auto block_sum2 = [&](float &pa, float &pb) { // both sums over the workgroup, same value in every thread
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                    pa += __shfl_xor(pa, o2, 64);
+                    pb += __shfl_xor(pb, o2, 64);
+                }
+                if ((tl & 63) == 0) {
+                    s_red[4 + 2 * (tl >> 6)] = pa;
+                    s_red[5 + 2 * (tl >> 6)] = pb;
+                }
+                __syncthreads();
+                pa = 0.0f;
+                pb = 0.0f;
+#pragma unroll
+                for (int w = 0; w < G::WAVES; ++w) {
+                    pa += s_red[4 + 2 * w];
+                    pb += s_red[5 + 2 * w];
+                }
+                __syncthreads(); // s_red is reused by the second sum
+            };
+            auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
+            const float rl = r4(lo[0]) + r4(lo[1]), ru = r4(up[0]) + r4(up[1]), rn = r4(nl[0]) + r4(nl[1]);
+            float ra = rl + ru, rb = ru + rn;
+            block_sum2(ra, rb);
+            oa = ra * (1.0f / (float)N);
+            ob = rb * (1.0f / (float)N);
             auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
             float pa = s4(lo[0], oa) + s4(lo[1], oa) + s4(up[0], oa) + s4(up[1], oa);
             float pb = s4(up[0], ob) + s4(up[1], ob) + s4(nl[0], ob) + s4(nl[1], ob);
-#pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                pa += __shfl_xor(pa, o2, 64);
-                pb += __shfl_xor(pb, o2, 64);
-            }
-            if ((tl & 63) == 0) {
-                s_red[4 + 2 * (tl >> 6)] = pa;
-                s_red[5 + 2 * (tl >> 6)] = pb;
-            }
-            __syncthreads();
-            pa = 0.0f;
-            pb = 0.0f;
-#pragma unroll
-            for (int w = 0; w < G::WAVES; ++w) {
-                pa += s_red[4 + 2 * w];
-                pb += s_red[5 + 2 * w];
-            }
+            block_sum2(pa, pb);
             ma = pa * (1.0f / (float)N);
             mb = pb * (1.0f / (float)N);
         }

@@ -324,9 +324,16 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSE
                 sa = span_slope(oa, team_bcast<TEAM>(up[1].w, l0, TEAM - 1), N);
                 ob = team_bcast<TEAM>(up[0].x, l0, 0);
                 sb = span_slope(ob, team_bcast<TEAM>(nl[1].w, l0, TEAM - 1), N);
-            } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109), summed about the midpoint sample
-                oa = team_bcast<TEAM>(up[0].x, l0, 0);
-                ob = team_bcast<TEAM>(nl[0].x, l0, 0);
+            } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109) in two steps
+                // o = the f32 mean of the raw samples (a pivot close to the true mean: with a DC level
+                // far above the noise x - o is exact, without one it is a small number), m = the mean of
+                // the residuals x - o (tiny, so ITS rounding does not matter).  A single f32 offset
+                // would be rounded at ulp(|mean|), a pivot on a sample at ulp(|sample|) -- either is a
+                // coherent offset over the segment, i.e. an error in bins 0 and 1.
+                auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
+                const float rl = r4(lo[0]) + r4(lo[1]), ru = r4(up[0]) + r4(up[1]), rn = r4(nl[0]) + r4(nl[1]);
+                oa = team_sum<TEAM>(rl + ru) * (1.0f / (float)N);
+                ob = team_sum<TEAM>(ru + rn) * (1.0f / (float)N);
                 auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
                 const float sl = s4(lo[0], oa) + s4(lo[1], oa);
                 const float sua = s4(up[0], oa) + s4(up[1], oa);

@@ -130,39 +130,50 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 ob = xb[0];
                 sb = span_slope(ob, xb[N - 1], N);
             }
-        } else if (detrend == 3) { // Mean :103-109, summed about the midpoint sample (pivot)
-            const float va = act_a ? xa[N / 2] : 0.0f, vb = act_b ? xb[N / 2] : 0.0f;
+        } else if (detrend == 3) { // Mean :103-109 in two steps: o = f32 mean of the samples, m = mean of x - o
+            // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
+            auto team_sum2 = [&](float &pa, float &pb) {
+                constexpr int W = TEAM < 64 ? TEAM : 64;
+#pragma unroll
+                for (int o = W / 2; o > 0; o >>= 1) {
+                    pa += __shfl_xor(pa, o);
+                    pb += __shfl_xor(pb, o);
+                }
+                if constexpr (TEAM > 64) {
+                    // a team spans TEAM / 64 wavefronts: combine exactly those through LDS
+                    constexpr int WPT = TEAM / 64;
+                    const int w = threadIdx.x >> 6;
+                    if ((threadIdx.x & 63) == 0) {
+                        red[2 * w] = pa;
+                        red[2 * w + 1] = pb;
+                    }
+                    __syncthreads();
+                    pa = 0.0f;
+                    pb = 0.0f;
+                    for (int i = 0; i < WPT; ++i) {
+                        pa += red[2 * (team * WPT + i)];
+                        pb += red[2 * (team * WPT + i) + 1];
+                    }
+                    __syncthreads();
+                }
+            };
             float pa = 0.0f, pb = 0.0f;
 #pragma unroll
             for (int s = 0; s < E; ++s) {
-                pa += ra[s] - va;
-                pb += rb[s] - vb;
+                pa += ra[s];
+                pb += rb[s];
             }
-            constexpr int W = TEAM < 64 ? TEAM : 64;
+            team_sum2(pa, pb);
+            oa = pa / (float)N;
+            ob = pb / (float)N;
+            pa = 0.0f;
+            pb = 0.0f;
 #pragma unroll
-            for (int o = W / 2; o > 0; o >>= 1) {
-                pa += __shfl_xor(pa, o);
-                pb += __shfl_xor(pb, o);
+            for (int s = 0; s < E; ++s) {
+                pa += ra[s] - oa;
+                pb += rb[s] - ob;
             }
-            if constexpr (TEAM > 64) {
-                // a team spans TEAM / 64 wavefronts: combine exactly those through LDS
-                constexpr int WPT = TEAM / 64;
-                const int w = threadIdx.x >> 6;
-                if ((threadIdx.x & 63) == 0) {
-                    red[2 * w] = pa;
-                    red[2 * w + 1] = pb;
-                }
-                __syncthreads();
-                pa = 0.0f;
-                pb = 0.0f;
-                for (int i = 0; i < WPT; ++i) {
-                    pa += red[2 * (team * WPT + i)];
-                    pb += red[2 * (team * WPT + i) + 1];
-                }
-                __syncthreads();
-            }
-            oa = va;
-            ob = vb;
+            team_sum2(pa, pb);
             ma = pa / (float)N;
             mb = pb / (float)N;
         }
