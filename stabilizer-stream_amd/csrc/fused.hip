@@ -74,7 +74,7 @@ __device__ __forceinline__ float team_sum(float v)
 // The Span / Mean / EWMA variants need a few more registers than the 128 that four
 // wavefronts per SIMD allow; they are built for two per SIMD rather than spilling.
 template <int N, int DETREND, bool EWMA>
-__global__ __launch_bounds__(FUSED_WAVES * 64, (DETREND >= 2 || EWMA) ? 2 : FUSED_WAVES_PER_SIMD) void fused_kernel(
+__global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) void fused_kernel(
     const FusedBatch batch, const float *__restrict__ win)
 {
     using G = FusedGeo<N>;
