@@ -1,8 +1,11 @@
 // bigfused_impl.h -- the fused hot kernel for N = 2048 ... 16384 (Hann): the same single
 // pass over the stream as fused.hip (detrend + window + two-for-one FFT + |Z|^2, and the /8
-// half-band decimation of the same samples), with a whole workgroup of N/16 threads as the
-// team: the (4, RA, RB, 16) FFT of fft_block.h, hand-offs by workgroup barriers, window and
-// the two large twiddle tables read from global memory (L2 resident), the small one in LDS.
+// half-band decimation of the same samples), with a whole workgroup as the team: the
+// (4, RA, RB, 16) FFT of fft_block.h over N/16 "lanes" of 16 elements, hand-offs by workgroup
+// barriers, window and the two large twiddle tables read from global memory (L2 resident), the
+// small one in LDS.  A thread plays VT lanes (tl = thread + THREADS v): VT = 1 up to N = 8192;
+// N = 16384 uses VT = 2, i.e. 512 threads with 32 elements each -- its 1024-lane team as 1024
+// threads would be capped at 128 VGPRs (16 wavefronts on one CU) and spilled ~450 bytes per lane.
 // Each bigfused_<N>.hip instantiates one size.
 #pragma once
 #include "fft_block.h"
@@ -13,29 +16,36 @@ namespace psdk {
 template <int N>
 struct BigGeo : FusedDec<N> {
     using T = BlockFft<N>;
-    static constexpr int TEAM = T::TEAM;
-    static constexpr int WAVES = TEAM / 64;
+    static constexpr int TEAM = T::TEAM;          // lanes of the team
+    static constexpr int VT = N >= 16384 ? 2 : 1; // lanes per thread
+    static constexpr int THREADS = TEAM / VT;
+    static constexpr int WAVES = THREADS / 64;
+    // wavefronts per SIMD the kernel is built for (register budget 512 / WPS) and workgroups per CU
+    static constexpr int WPS = N >= 16384 ? 2 : BIG_WAVES_PER_SIMD;
+    static constexpr int BLOCKS_PER_CU = (4 * WPS / WAVES) > 0 ? (4 * WPS / WAVES) : 1;
     static constexpr int SCR = 2 * T::FRAME;
     static_assert(FusedDec<N>::END <= SCR && FusedDec<N>::WEND <= SCR, "decimator arrays exceed the frame");
+    static_assert(THREADS >= FusedDec<N>::HIST, "one carried filter-state element per thread at most");
 };
 
-// DETREND / EWMA as in fused.hip
-// Built for two wavefronts per SIMD (the global window / twiddle loads are hoisted early and
-// need the registers); N = 16384 has a 1024-thread workgroup and therefore 128 VGPRs at most.
+// DETREND / EWMA as in fused.hip.  Built for two wavefronts per SIMD (the global window / twiddle
+// loads are hoisted early and need the registers).
 template <int N, int DETREND, bool EWMA>
-__global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(const FusedBatch batch, const float *__restrict__ win,
-                                                         const cf *__restrict__ tw0g, const cf *__restrict__ twag)
+__global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_kernel(const FusedBatch batch,
+                                                                         const float *__restrict__ win,
+                                                                         const cf *__restrict__ tw0g,
+                                                                         const cf *__restrict__ twag)
 {
     using G = BigGeo<N>;
     using T = BlockFft<N>;
-    constexpr int TEAM = G::TEAM;
+    constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
     __shared__ cf s_frame[T::FRAME];
     __shared__ cf s_twb[T::TWB_SIZE];
     __shared__ float s_hist[G::HIST];
     __shared__ float s_red[2 * G::WAVES + 4];
 
-    const int tl = threadIdx.x;
-    for (int i = tl; i < T::TWB_SIZE; i += TEAM) { // [(q-1)][s]: W_SA^(s q)
+    const int tp = threadIdx.x; // lane v of this thread is tl = tp + THREADS v
+    for (int i = tp; i < T::TWB_SIZE; i += THREADS) { // [(q-1)][s]: W_SA^(s q)
         const int q = i / 16 + 1, s = i % 16;
         float sn, cs;
         sincospif(-2.0f * (float)(s * q) / (float)T::SA, &sn, &cs);
@@ -56,37 +66,44 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
     const float ta[HBF_MA] = {PSDK_HBF_TAPS_A};
     const float tb[HBF_MB] = {PSDK_HBF_TAPS_B};
     const float tc[HBF_MC] = {PSDK_HBF_TAPS_C};
-    const unsigned h_pack = G::hist_slot(tl); // TEAM >= 128 > 80: one carried element per thread at most
+    const unsigned h_pack = G::hist_slot(tp); // THREADS >= 128 > 80: one carried element per thread at most
 
-    float q[16];
+    float q[VT][16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        q[s] = 0.0f;
+    for (int v = 0; v < VT; ++v)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            q[v][s] = 0.0f;
 
     // this workgroup's run: pairs [p0, p0 + run) of the job (cut by npairs)
     const int p0 = wb * run;
     const int p1 = min(npairs, p0 + run);
-    const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tl;
+    const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tp;
     const float4 *safe = cp; // look-ahead target once nothing is left to look ahead to
-    float4 ga[2], gb[2], gc[2];
-    ga[0] = cp[0];
-    ga[1] = cp[TEAM];
-    gb[0] = cp[2 * TEAM];
-    gb[1] = cp[3 * TEAM];
-    gc[0] = cp[N / 4];
-    gc[1] = cp[N / 4 + TEAM];
+    // register groups of a lane: two float4 each (see pair_step)
+    float4 ga[VT][2], gb[VT][2], gc[VT][2];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const float4 *c = cp + THREADS * v;
+        ga[v][0] = c[0];
+        ga[v][1] = c[TEAM];
+        gb[v][0] = c[2 * TEAM];
+        gb[v][1] = c[3 * TEAM];
+        gc[v][0] = c[N / 4];
+        gc[v][1] = c[N / 4 + TEAM];
+    }
 
     // ---- warm-up: filter state at the first new sample of the run (hop >= 1024 > 288, so the
     // history is always inside the run's own first chunk) ------------------------------------
     {
         const float *xn = job.src + (size_t)p0 * N + N / 2;
-        for (int r = tl; r < G::WX / 2; r += TEAM) {
+        for (int r = tp; r < G::WX / 2; r += THREADS) {
             const int i0 = 2 * r - G::WX;
             sf[G::WXE + r] = xn[i0];
             sf[G::WXO + r] = xn[i0 + 1];
         }
         __syncthreads();
-        for (int u = tl; u < G::WA / 2; u += TEAM) {
+        for (int u = tp; u < G::WA / 2; u += THREADS) {
             float y0, y1;
             hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::WXE, sf + G::WXO, 2 * u, ta, y0, y1);
             sf[G::WAE + u] = y0;
@@ -97,7 +114,7 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             }
         }
         __syncthreads();
-        for (int u = tl; u < G::WB / 2; u += TEAM) {
+        for (int u = tp; u < G::WB / 2; u += THREADS) {
             float y0, y1;
             hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::WAE, sf + G::WAO, 2 * u, tb, y0, y1);
             hs[22 + u] = y0;
@@ -106,12 +123,29 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
         __syncthreads();
     }
 
+    // With several lanes per thread the scheduler must not interleave their sections (it would keep
+    // every lane's butterflies and twiddles live at once): a scheduling barrier between lanes.
+    auto lane_fence = [] {
+        if constexpr (VT > 1)
+            __builtin_amdgcn_sched_barrier(0);
+    };
+
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
-    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool more,
+    auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, bool more,
                          float *o, int p) {
+        // The window and twiddle tables are the same for every pair, and the compiler keeps all of a
+        // lane's entries (8 + 30 + 16 registers) live across the whole run.  With one lane per thread
+        // that fits the 256 registers of two wavefronts per SIMD and is the fastest arrangement
+        // (measured: re-loading per pair costs 2-5 % even at twice the occupancy); with two lanes per
+        // thread it does not fit, so there the table pointers are re-derived per pair, which keeps the
+        // loads inside the pair (L1 / L2 hits).
+        const cf *tw0p = tw0g, *twap = twag;
+        const float *winp = win;
+        if constexpr (VT > 1)
+            asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
         // ---- decimator ------------------------------------------------------------------
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            sf[h_pack & 0xFFFFu] = hs[tl];
+            sf[h_pack & 0xFFFFu] = hs[tp];
         // samples -> polyphase arrays as single floats (ds_write2_b32 from the registers the loads
         // filled; an 8-byte store of {x, z} would cost moves right behind the loads)
         auto split = [&](int h, const float4 &x) {
@@ -120,19 +154,21 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             sf[G::XO + h] = x.y;
             sf[G::XO + h + 1] = x.w;
         };
-        if (tl >= TEAM - 3)
-            split(2 * (tl - (TEAM - 3)), lo[1]);
-        {
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int tl = tp + THREADS * v;
+            if (tl >= TEAM - 3)
+                split(2 * (tl - (TEAM - 3)), lo[v][1]);
             const int h = G::HX / 2 + 2 * tl;
-            split(h, up[0]);
-            split(h + N / 8, up[1]);
-            split(h + N / 4, nl[0]);
-            split(h + 3 * N / 8, nl[1]);
+            split(h, up[v][0]);
+            split(h + N / 8, up[v][1]);
+            split(h + N / 4, nl[v][0]);
+            split(h + 3 * N / 8, nl[v][1]);
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { // stage A
-            const int u = tl + TEAM * r;
+        for (int r = 0; r < 4 * VT; ++r) { // stage A: N/2 outputs, two per step
+            const int u = tp + THREADS * r;
             float y0, y1;
             hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
             sf[G::AE + 11 + u] = y0;
@@ -140,39 +176,40 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { // stage B
-            const int u = tl + TEAM * r;
+        for (int r = 0; r < 2 * VT; ++r) { // stage B: N/4 outputs
+            const int u = tp + THREADS * r;
             float y0, y1;
             hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 2 * u, tb, y0, y1);
             sf[G::BE + 29 + u] = y0;
             sf[G::BO + 29 + u] = y1;
         }
         __syncthreads();
-        { // stage C: N/8 outputs, two per thread
+#pragma unroll
+        for (int r = 0; r < VT; ++r) { // stage C: N/8 outputs, two per lane
+            const int u = tp + THREADS * r;
             float y0, y1;
-            hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tl, tc, y0, y1);
-            o[2 * tl] = y0;
-            o[2 * tl + 1] = y1;
+            hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * u, tc, y0, y1);
+            *reinterpret_cast<f2 *>(o + 2 * u) = {y0, y1};
         }
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            hs[tl] = sf[h_pack >> 16];
+            hs[tp] = sf[h_pack >> 16];
 
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
         float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
         slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
-        if constexpr (DETREND == 1) { // the segments' midpoint samples
-            if (tl == 0) {
-                s_red[0] = up[0].x;
-                s_red[1] = nl[0].x;
+        if constexpr (DETREND == 1) { // the segments' midpoint samples (lane 0)
+            if (tp == 0) {
+                s_red[0] = up[0][0].x;
+                s_red[1] = nl[0][0].x;
             }
-        } else if constexpr (DETREND == 2) {
-            if (tl == 0) {
-                s_red[0] = lo[0].x;
-                s_red[1] = up[0].x;
+        } else if constexpr (DETREND == 2) { // first (lane 0) and last (lane TEAM - 1) samples
+            if (tp == 0) {
+                s_red[0] = lo[0][0].x;
+                s_red[1] = up[0][0].x;
             }
-            if (tl == TEAM - 1) {
-                s_red[2] = up[1].w;
-                s_red[3] = nl[1].w;
+            if (tp == THREADS - 1) {
+                s_red[2] = up[VT - 1][1].w;
+                s_red[3] = nl[VT - 1][1].w;
             }
         }
         __syncthreads(); // the frame is reused by the FFT; s_red published
@@ -193,9 +230,9 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
                     pa += __shfl_xor(pa, o2, 64);
                     pb += __shfl_xor(pb, o2, 64);
                 }
-                if ((tl & 63) == 0) {
-                    s_red[4 + 2 * (tl >> 6)] = pa;
-                    s_red[5 + 2 * (tl >> 6)] = pb;
+                if ((tp & 63) == 0) {
+                    s_red[4 + 2 * (tp >> 6)] = pa;
+                    s_red[5 + 2 * (tp >> 6)] = pb;
                 }
                 __syncthreads();
                 pa = 0.0f;
@@ -208,29 +245,41 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
                 __syncthreads(); // s_red is reused by the second sum
             };
             auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
-            const float rl = r4(lo[0]) + r4(lo[1]), ru = r4(up[0]) + r4(up[1]), rn = r4(nl[0]) + r4(nl[1]);
-            float ra = rl + ru, rb = ru + rn;
+            float ra = 0.0f, rb = 0.0f;
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const float rl = r4(lo[v][0]) + r4(lo[v][1]), ru = r4(up[v][0]) + r4(up[v][1]);
+                const float rn = r4(nl[v][0]) + r4(nl[v][1]);
+                ra += rl + ru;
+                rb += ru + rn;
+            }
             block_sum2(ra, rb);
             oa = ra * (1.0f / (float)N);
             ob = rb * (1.0f / (float)N);
             auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
-            float pa = s4(lo[0], oa) + s4(lo[1], oa) + s4(up[0], oa) + s4(up[1], oa);
-            float pb = s4(up[0], ob) + s4(up[1], ob) + s4(nl[0], ob) + s4(nl[1], ob);
+            float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                pa += s4(lo[v][0], oa) + s4(lo[v][1], oa) + s4(up[v][0], oa) + s4(up[v][1], oa);
+                pb += s4(up[v][0], ob) + s4(up[v][1], ob) + s4(nl[v][0], ob) + s4(nl[v][1], ob);
+            }
             block_sum2(pa, pb);
             ma = pa * (1.0f / (float)N);
             mb = pb * (1.0f / (float)N);
         }
 
         // ---- FFT of the pair ---------------------------------------------------------------
-        cf v[16];
-        {
-            float ea = 1.0f, eb = 1.0f;
-            if constexpr (EWMA) {
-                if (job.ewma) {
-                    ea = fused_ewma_amp(job, job.step0 + 2 * p);
-                    eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
-                }
+        cf vv[VT][16];
+        float ea = 1.0f, eb = 1.0f;
+        if constexpr (EWMA) {
+            if (job.ewma) {
+                ea = fused_ewma_amp(job, job.step0 + 2 * p);
+                eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
             }
+        }
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int tl = tp + THREADS * v;
             const float nf = (float)(4 * tl);
             auto put = [&](int slot, float xa, float xb, float w, int nofs) {
                 if constexpr (DETREND == 1) {
@@ -250,11 +299,11 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
                     xa *= ea;
                     xb *= eb;
                 }
-                v[slot] = {xa, xb};
+                vv[v][slot] = {xa, xb};
             };
-            const float4 *wp = reinterpret_cast<const float4 *>(win) + tl;
+            const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
             const float4 w0 = wp[0], w1 = wp[TEAM], w2 = wp[2 * TEAM], w3 = wp[3 * TEAM];
-            const float4 a0 = lo[0], a1 = lo[1], a2 = up[0], a3 = up[1], b2 = nl[0], b3 = nl[1];
+            const float4 a0 = lo[v][0], a1 = lo[v][1], a2 = up[v][0], a3 = up[v][1], b2 = nl[v][0], b3 = nl[v][1];
             put(0, a0.x, a2.x, w0.x, 0);
             put(1, a0.y, a2.y, w0.y, 1);
             put(2, a0.z, a2.z, w0.z, 2);
@@ -271,33 +320,52 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
             put(13, a3.y, b3.y, w3.y, 3 * N / 4 + 1);
             put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
             put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
+            // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
+            // go one after the other between two barriers)
+            T::pass0(tl, vv[v], tw0p);
+            T::store0(tl, vv[v], frame);
+            lane_fence();
         }
         { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT; issued
           // unconditionally (after the last pair: re-reads of pieces read before, unused) so that
           // the compiler does not wait for them at the end of a branch
             const float4 *src = more ? cnext : safe;
             safe = src;
-            up[0] = src[2 * TEAM];
-            up[1] = src[3 * TEAM];
-            lo[0] = src[N / 4];
-            lo[1] = src[N / 4 + TEAM];
-        }
-        T::pass0(tl, v, tw0g);
-        T::store0(tl, v, frame);
-        __syncthreads();
-        T::loadA(tl, v, frame);
-        T::passA(tl, v, twag);
-        T::storeA(tl, v, frame); // in place: each thread rewrites exactly what it read
-        __syncthreads();
-        T::loadB(tl, v, frame);
-        T::passB(tl, v, s_twb);
-        T::storeB(tl, v, frame);
-        __syncthreads();
-        T::loadC(tl, v, frame);
-        T::passC(v);
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+            for (int v = 0; v < VT; ++v) {
+                const float4 *c = src + THREADS * v;
+                up[v][0] = c[2 * TEAM];
+                up[v][1] = c[3 * TEAM];
+                lo[v][0] = c[N / 4];
+                lo[v][1] = c[N / 4 + TEAM];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            T::loadA(tp + THREADS * v, vv[v], frame);
+            T::passA(tp + THREADS * v, vv[v], twap);
+            T::storeA(tp + THREADS * v, vv[v], frame);
+            lane_fence();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            T::loadB(tp + THREADS * v, vv[v], frame);
+            T::passB(tp + THREADS * v, vv[v], s_twb);
+            T::storeB(tp + THREADS * v, vv[v], frame);
+            lane_fence();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            T::loadC(tp + THREADS * v, vv[v], frame);
+            T::passC(vv[v]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                q[v][s] = fmaf(vv[v][s].re, vv[v][s].re, fmaf(vv[v][s].im, vv[v][s].im, q[v][s]));
+            lane_fence();
+        }
         __syncthreads(); // next pair's decimator writes the frame
     };
 
@@ -318,14 +386,16 @@ __global__ __launch_bounds__(N / 16, N < 16384 ? 2 : 4) void bigfused_kernel(con
     // one team per workgroup: its accumulators are the partial
     float *out = job.partial + (size_t)wb * N;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        out[T::freq_of(tl, s)] = q[s];
+    for (int v = 0; v < VT; ++v)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            out[T::freq_of(tp + THREADS * v, s)] = q[v][s];
 }
 
 template <int N>
 hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
 {
-    const dim3 grid(b.nblocks), block(N / 16);
+    const dim3 grid(b.nblocks), block(BigGeo<N>::THREADS);
 #define PSDK_BIG_CASE(D)                                                                          \
     case D:                                                                                       \
         if (b.any_ewma)                                                                           \

@@ -16,6 +16,7 @@
 //   - adds |Z|^2 into 16 registers per lane.
 // LDS operations of one wavefront execute in order, so inside a run only compiler-level
 // ordering is needed: there is no workgroup barrier in the loop.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -499,15 +500,17 @@ int fused_pairs_per_block(int n, int run)
 // resident workgroups the launch is sized for (per CU: LDS and thread limits of each size)
 int fused_max_blocks(int n)
 {
+    // workgroups per CU of the workgroup-level kernels: 4 SIMDs x wavefronts per SIMD / wavefronts per workgroup
+    auto big = [](int threads, int wps) { return 256 * std::max(1, 4 * wps / (threads / 64)); };
     switch (n) {
     case 2048:
-        return 256 * 4; // 128 threads, 17 KB of LDS, 2 wavefronts per SIMD
+        return big(128, BIG_WAVES_PER_SIMD); // 17 KB of LDS each
     case 4096:
-        return 256 * 2; // 256 threads, 35 KB
+        return big(256, BIG_WAVES_PER_SIMD); // 35 KB
     case 8192:
-        return 256; // 512 threads, 70 KB
+        return big(512, BIG_WAVES_PER_SIMD); // 70 KB
     case 16384:
-        return 256; // 1024 threads, 139 KB
+        return 256; // 512 threads x 2 lanes, 139 KB
     default:
         return 256 * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES); // 8 wavefronts, <= 80 KB: two per CU
     }

@@ -109,6 +109,10 @@ struct FusedBatch {
 #ifndef PSDK_FUSED_WPS
 #define PSDK_FUSED_WPS 4
 #endif
+#ifndef PSDK_BIG_WPS
+#define PSDK_BIG_WPS 2
+#endif
+constexpr int BIG_WAVES_PER_SIMD = PSDK_BIG_WPS;     // N = 2048 ... 8192 kernels: wavefronts per SIMD they are built for
 constexpr int FUSED_WAVES = PSDK_FUSED_WAVES;        // wavefronts per workgroup
 constexpr int FUSED_WAVES_PER_SIMD = PSDK_FUSED_WPS; // launch bound: wavefronts per SIMD
 
