@@ -102,6 +102,7 @@ def main():
     args = ap.parse_args()
 
     import torch
+    torch.set_num_threads(1)  # no CPU tensor math here; keep torch's thread pool out of the timed loop
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +164,13 @@ def main():
     # read-out: every rank's raw per-stage accumulators + counters to rank 0 in ONE RCCL gather,
     # then the host stitch (PsdCascade::psd) per channel on rank 0
     ns = bank.num_stages(0)
+    if os.environ.get("PSD_BENCH_DEBUG"):
+        t_drain = time.perf_counter() - t0
+        bank.read_channel(0)  # debug only: the C-ABI part of the read-out alone
+        t_rc = time.perf_counter() - t0
     spec, meta = shard.pack_readout(bank, C, n, torch)
+    if os.environ.get("PSD_BENCH_DEBUG"):
+        t_pack = time.perf_counter() - t0
     if dist is not None:
         specs, metas = shard.gather_readout(
             dist, spec, meta, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
@@ -175,7 +182,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if os.environ.get("PSD_BENCH_DEBUG"):
-        print(f"[debug] enqueue {host_enqueue_s*1e3:.2f} ms, +sync {t_sync*1e3:.2f} ms, +readout {t_read*1e3:.2f} ms, "
+        print(f"[debug] enqueue {host_enqueue_s*1e3:.2f} ms, +sync {t_sync*1e3:.2f} ms, +drain {t_drain*1e3:.2f} ms, +read_channel {t_rc*1e3:.2f} ms, "
+              f"+pack {t_pack*1e3:.2f} ms, +readout {t_read*1e3:.2f} ms, "
               f"total {dt*1e3:.2f} ms", file=sys.stderr)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")

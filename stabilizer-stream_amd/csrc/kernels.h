@@ -145,6 +145,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);
+// device -> pinned host copy by a kernel (read-outs; see kernels.hip)
+hipError_t launch_copy_out(float *h_dst, const float *d_src, size_t count, hipStream_t s);
 // frames: device copy of n_frames frames of frame_size bytes (AdcDac, `batches`
 // batches each); dst[c] receives 8*batches*n_frames samples of trace c.
 hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,

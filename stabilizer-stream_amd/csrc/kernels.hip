@@ -492,6 +492,26 @@ hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s
     return hipGetLastError();
 }
 
+// Read-out copy device -> pinned host memory by the shader cores (the host pointer is device
+// visible): the copy engines the runtime would use for a D2H hipMemcpyAsync sometimes take
+// milliseconds to wake after a compute-only stretch, which a read-out in a timed loop cannot afford.
+__global__ __launch_bounds__(256) void copy_out_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < count; k += stride)
+        dst[k] = src[k];
+}
+
+hipError_t launch_copy_out(float *h_dst, const float *d_src, size_t count, hipStream_t s)
+{
+    if (count == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (count + 255) / 256);
+    hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, s, h_dst, d_src, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s)
 {
     if (len == 0)

@@ -961,7 +961,7 @@ int read_back(psdc_handle *h, float *dst, const float *d_src, size_t count)
     const size_t chunk = (size_t)MAX_STAGES * h->n;
     while (count > 0) {
         const size_t m = std::min(count, chunk);
-        HIPCHK(h, hipMemcpyAsync(h->h_read, d_src, sizeof(float) * m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, launch_copy_out(h->h_read, d_src, m, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         memcpy(dst, h->h_read, sizeof(float) * m);
         dst += m;
@@ -1151,12 +1151,11 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_read), sizeof(float) * (size_t)MAX_STAGES * n,
                            hipHostMallocDefault)) != hipSuccess)
         return dev_fail(e, "hipHostMalloc(read-out)");
-    // one full-size read through the pinned buffer now: the runtime initialises its device-to-host
-    // copy engine path lazily (several ms on the first copy above ~16 KB), which does not belong in
-    // the first psd() of a live stream
+    // one full-size read through the pinned buffer now (read-outs copy with a kernel that writes
+    // the pinned host buffer directly, see launch_copy_out): first-use costs do not belong in the
+    // first psd() of a live stream
     if ((e = hipMemsetAsync(h->d_spectra, 0, sizeof(float) * (size_t)MAX_STAGES * n, h->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(h->h_read, h->d_spectra, sizeof(float) * (size_t)MAX_STAGES * n, hipMemcpyDeviceToHost,
-                            h->stream)) != hipSuccess ||
+        (e = launch_copy_out(h->h_read, h->d_spectra, (size_t)MAX_STAGES * n, h->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(h->stream)) != hipSuccess)
         return dev_fail(e, "read-out warm-up");
     h->pool_cap = (size_t)4 * (n + HBF_HALO) + 64;
@@ -1682,8 +1681,7 @@ int psdc_read_channel(psdc_handle *h, uint32_t channel, uint32_t cap, uint32_t *
             stats[k].processed = (uint64_t)h->n * s.count - (uint64_t)h->geo.overlap * cm1;
         }
     if (spectra && ns) { // the channel's accumulators are consecutive rows of one slab: one copy
-        HIPCHK(h, hipMemcpyAsync(h->h_read, c.st[0].spectrum, sizeof(float) * (size_t)ns * h->n,
-                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, launch_copy_out(h->h_read, c.st[0].spectrum, (size_t)ns * h->n, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         const size_t bins = h->n / 2 + 1;
         for (uint32_t k = 0; k < ns; ++k)
@@ -1714,8 +1712,7 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
         pend[i] = pending_for(h->geo, c.st[i].total);
     }
     if (psd_out && ns) {
-        HIPCHK(h, hipMemcpyAsync(h->h_read, c.st[0].spectrum, sizeof(float) * ns * h->n, hipMemcpyDeviceToHost,
-                                 h->stream));
+        HIPCHK(h, launch_copy_out(h->h_read, c.st[0].spectrum, ns * h->n, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (size_t i = 0; i < ns; ++i)
             memcpy(spectra.data() + i * bins, h->h_read + i * h->n, sizeof(float) * bins);

@@ -18,11 +18,16 @@ def channel_shard(n_channels, world, rank):
     return list(range(lo, lo + base + (1 if rank < rem else 0)))
 
 
-def pack_readout(bank, n_local, n, torch):
-    """Raw spectra [n_local, KMAX, n/2+1] f32 and (count, avg, pending, valid) [n_local, KMAX, 4] i64."""
+def pack_readout(bank, n_local, n, torch=None, pad_to=None):
+    """Raw spectra [rows, KMAX, n/2+1] f32 and (count, avg, pending, valid) [rows, KMAX, 4] i64 as numpy
+    arrays, rows = max(n_local, pad_to) (ranks must gather equally shaped blocks: pad to the largest
+    shard).  Plain numpy on purpose: the read-out sits inside timed loops, and small CPU tensor
+    ops in torch were seen to stall for tens of ms now and then (thread-pool wake-ups) on the many-core
+    GPU hosts.  `torch` is accepted for compatibility and not used."""
     bins = n // 2 + 1
-    spec = torch.zeros(n_local, KMAX, bins, dtype=torch.float32)
-    meta = torch.zeros(n_local, KMAX, 4, dtype=torch.int64)
+    rows = max(n_local, pad_to or 0)
+    spec = np.zeros((rows, KMAX, bins), dtype=np.float32)
+    meta = np.zeros((rows, KMAX, 4), dtype=np.int64)
     for c in range(n_local):
         if hasattr(bank, "read_channel"):  # one flush + one copy per channel
             infos, sp = bank.read_channel(c)
@@ -31,19 +36,21 @@ def pack_readout(bank, n_local, n, torch):
             sp = np.stack([bank.stage_spectrum(c, k) for k in range(len(infos))]) if infos else np.zeros((0, bins))
         assert len(infos) <= KMAX
         if len(infos):
-            spec[c, :len(infos)] = torch.from_numpy(np.ascontiguousarray(sp, dtype=np.float32))
+            spec[c, :len(infos)] = sp
         for k, info in enumerate(infos):
-            meta[c, k, 0], meta[c, k, 1], meta[c, k, 2], meta[c, k, 3] = info["count"], info["avg"], info["pending"], 1
+            meta[c, k] = (info["count"], info["avg"], info["pending"], 1)
     return spec, meta
 
 
 def gather_readout(dist, spec, meta, device=None, dst=0):
-    """One gather of (spec, meta) to rank `dst`.  All ranks must hold equally shaped tensors
-    (pad channel blocks to the largest shard).  Returns lists on dst, (None, None) elsewhere."""
+    """One gather of (spec, meta) to rank `dst`.  All ranks must hold equally shaped arrays
+    (numpy or CPU tensors).  Returns lists of numpy arrays on dst, (None, None) elsewhere."""
+    import torch
+    spec = torch.from_numpy(np.ascontiguousarray(np.asarray(spec), dtype=np.float32))
+    meta = torch.from_numpy(np.ascontiguousarray(np.asarray(meta), dtype=np.int64))
     if device is not None:
         spec, meta = spec.to(device), meta.to(device)
     rank, world = dist.get_rank(), dist.get_world_size()
-    import torch
     # a single payload: meta is carried as two exact f32 halves (values < 2^48 split into 24-bit words)
     lo = (meta & 0xFFFFFF).to(torch.float32)
     hi = (meta >> 24).to(torch.float32)
@@ -57,11 +64,11 @@ def gather_readout(dist, spec, meta, device=None, dst=0):
     nm = meta.shape[1] * meta.shape[2]
     specs, metas = [], []
     for p in out:
-        p = p.cpu()
-        specs.append(p[:, :nb].reshape(spec.shape))
-        lo_ = p[:, nb:nb + nm].to(torch.int64)
-        hi_ = p[:, nb + nm:nb + 2 * nm].to(torch.int64)
-        metas.append(((hi_ << 24) | lo_).reshape(meta.shape))
+        p = p.cpu().numpy()
+        specs.append(p[:, :nb].reshape(tuple(spec.shape)))
+        lo_ = p[:, nb:nb + nm].astype(np.int64)
+        hi_ = p[:, nb + nm:nb + 2 * nm].astype(np.int64)
+        metas.append(((hi_ << 24) | lo_).reshape(tuple(meta.shape)))
     return specs, metas
 
 
@@ -71,10 +78,11 @@ def stitch_gathered(pkg, n, specs, metas, counts_per_rank, opts=None, window=Non
     window = window if window is not None else pkg.Window.HANN
     results = []
     for r, (spec, meta) in enumerate(zip(specs, metas)):
+        spec, meta = np.asarray(spec), np.asarray(meta)
         for c in range(counts_per_rank[r]):
             ns = int(meta[c, :, 3].sum())
             counts = [int(v) for v in meta[c, :ns, 0]]
             avgs = [int(v) for v in meta[c, :ns, 1]]
             pend = [int(v) for v in meta[c, :ns, 2]]
-            results.append(pkg.stitch(n, counts, avgs, pend, spec[c, :ns].numpy(), opts, window))
+            results.append(pkg.stitch(n, counts, avgs, pend, np.ascontiguousarray(spec[c, :ns]), opts, window))
     return results

@@ -46,11 +46,7 @@ def _worker(rank, world, port, n, n_channels, total, out_path):
     streams = [pkg.noise_host(total + 1000 * g, 0x7654321 + g) for g in mine]
     bank = OracleBank(ora, n, streams)
     width = max(len(shard.channel_shard(n_channels, world, r)) for r in range(world))
-    spec, meta = shard.pack_readout(bank, len(mine), n, torch)
-    pad = width - len(mine)
-    if pad:
-        spec = torch.cat([spec, torch.zeros(pad, *spec.shape[1:])])
-        meta = torch.cat([meta, torch.zeros(pad, *meta.shape[1:], dtype=meta.dtype)])
+    spec, meta = shard.pack_readout(bank, len(mine), n, pad_to=width)  # equal blocks for the gather
     specs, metas = shard.gather_readout(dist, spec, meta)
     if rank == 0:
         per_rank = [len(shard.channel_shard(n_channels, world, r)) for r in range(world)]

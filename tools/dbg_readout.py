@@ -1,26 +1,31 @@
-import sys, time, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""Where does a slow read-out spend its time?  Repeats (feed K steps, read out) and times the pieces."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
 import __graft_entry__ as entry
-import torch, numpy as np
 pkg = entry.load_package()
-n, T = int(os.environ.get("PSD_N", "1024")), 1 << 26
-bank = pkg.PsdCascadeBank(n, 1)
-d = torch.empty(T, dtype=torch.float32, device="cuda")
-pkg.fill_noise_device(d.data_ptr(), T, seed=1)
-for _ in range(63):
-    bank.process_device(0, d.data_ptr(), T)
-bank.sync()
-def tm(label, f):
-    t = time.perf_counter(); r = f(); print(f"{label}: {(time.perf_counter()-t)*1e3:.3f} ms"); return r
-tm("import shard", lambda: __import__("stabilizer_stream_amd.shard"))
-from stabilizer_stream_amd import shard
-tm("num_stages", lambda: bank.num_stages(0))
-tm("read_channel #1", lambda: bank.read_channel(0))
-tm("read_channel #2", lambda: bank.read_channel(0))
-tm("stage_spectrum", lambda: bank.stage_spectrum(0, 0))
-tm("stage_info", lambda: bank.stage_info(0, 0))
-spec, meta = tm("pack_readout", lambda: shard.pack_readout(bank, 1, n, torch))
-tm("stitch", lambda: shard.stitch_gathered(pkg, n, [spec], [meta], [1]))
-tm("psd", lambda: bank.psd(0))
-tm("process+sync", lambda: (bank.process_device(0, d.data_ptr(), T), bank.sync()))
-tm("read_channel #3", lambda: bank.read_channel(0))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+T = 1 << 26
+x = torch.empty(T, dtype=torch.float32, device="cuda")
+pkg.fill_noise_device(x.data_ptr(), T, seed=1)
+torch.cuda.synchronize()
+for rep in range(reps):
+    bank = pkg.PsdCascadeBank(n, 1)
+    for i in range(3):
+        bank.process_device(0, x.data_ptr(), T)
+    bank.read_channel(0)
+    for i in range(30):
+        bank.process_device(0, x.data_ptr(), T)
+    t0 = time.perf_counter()
+    bank.flush()              # enqueue the drain rounds (no wait)
+    t1 = time.perf_counter()
+    bank.sync()               # wait for them
+    t2 = time.perf_counter()
+    ns = bank.num_stages(0)
+    t3 = time.perf_counter()
+    infos, sp = bank.read_channel(0)
+    t4 = time.perf_counter()
+    print(f"rep {rep}: flush {1e3*(t1-t0):.2f} ms, sync {1e3*(t2-t1):.2f}, num_stages {1e3*(t3-t2):.2f}, read_channel {1e3*(t4-t3):.2f}", flush=True)
+    bank.close()
