@@ -432,6 +432,40 @@ def test_feed_the_reference_panics_on(pkg, ora, gpu_required):
     g.close()
 
 
+def test_two_handles_two_threads(pkg, ora, gpu_required):
+    """Distinct handles are independent and each is used from one thread at a time, as the
+    reference's cascades are (`Send`, not `Sync`; src/bin/psd.rs:168-176 creates them inside the
+    receiver thread): two host threads feed their own handle concurrently (large host-fed calls
+    compete for the shared staging-copy workers) and both must match their oracle."""
+    import threading
+    n = 1024
+    xs = [pkg.noise_host((1 << 23) + 777 * (i + 1), seed=500 + i) for i in range(2)]
+    banks = [pkg.PsdCascadeBank(n, 1) for _ in range(2)]
+    errs = []
+
+    def work(i):
+        try:
+            x = xs[i]
+            cuts = [0, 3_000_000 + 11 * i, 3_000_500 + 11 * i, 7_000_001, x.size]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                banks[i].process(0, x[a:b])
+                if b == cuts[2]:
+                    banks[i].num_stages(0)  # a mid-stream read-out on this thread
+            banks[i].sync()
+        except Exception as e:  # surfaced below, in the main thread
+            errs.append((i, e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        check_against_oracle(pkg, ora, banks[i], [xs[i]], n, what=f"thread {i}")
+        banks[i].close()
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch
