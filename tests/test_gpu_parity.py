@@ -466,6 +466,21 @@ def test_two_handles_two_threads(pkg, ora, gpu_required):
         banks[i].close()
 
 
+def test_cpp_mirror_stream_test_flow(pkg, gpu_required):
+    """The reference's stream_test flow (src/bin/stream_test.rs:38-66) through the C++ mirror
+    cpp/psd_cascade.hpp: four PsdCascade<512> with Detrend::Midpoint, 176-sample traces, clone,
+    psd(), Break::frequencies; white noise must read PSD = 2 within the reference's own bound
+    (src/psd.rs:634-643) and Detrend::Linear must throw (unimplemented!(), src/psd.rs:110)."""
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "host")
+    exe = os.path.join(host, "cpp_mirror_check")
+    if not os.path.exists(exe):  # built by __graft_entry__.build(); the GPU box has no need to rebuild
+        subprocess.run(["make", "-C", host, "cpp_mirror_check"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 out of bound, Linear throws" in r.stdout, r.stdout[-2000:]
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch

@@ -63,6 +63,15 @@ def test_host_programs(pkg):
     assert m.group(1) == m.group(2) and m.group(3) == m.group(4), line
 
 
+def test_cpp_mirror_builds_against_the_abi(pkg):
+    """cpp/psd_cascade.hpp (the header-only C++ mirror of PsdCascade / Break / MergeOpts) compiles
+    and links against include/psdcascade.h + libpsdcascade.so: tests/host/cpp_mirror_check.cpp is the
+    reference's stream_test flow written with it (run on the GPU by test_gpu_parity)."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.run(["make", "-C", host, "cpp_mirror_check"], check=True, stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(host, "cpp_mirror_check"))
+
+
 @pytest.mark.parametrize("n,window", [(16, "hann"), (64, "hann"), (512, "hann"), (1024, "hann"),
                                       (128, "rect"), (4096, "hann")])
 def test_plan_counts_match_the_oracle(pkg, ora, n, window):
