@@ -576,12 +576,13 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     }
 
     // ---- turn the work into kernel jobs ---------------------------------
-    // Fast path (fused1024_kernel): whole segment pairs of an N = 1024 Hann stream with
-    // Detrend::None and plain-sum averaging, 16-byte aligned.  Everything else -- other N,
-    // detrend, EWMA, an odd last segment, the decimator ranges a pair does not cover (the
-    // first segment of a stream is decimated whole, src/psd.rs:235-238; zero-copy seams) --
-    // goes through the generic welch / hbf_dec8 kernels.  Both write the same partial slab
-    // and next-stage stream, so the reduce and the bookkeeping do not care which ran.
+    // Fast path (fused_kernel / bigfused_kernel): whole segment pairs of a Hann stream with
+    // N = 256 ... 16384, any implemented detrend, plain-sum or EWMA averaging, 16-byte aligned.
+    // Everything else -- other N, the rectangular window, an odd last segment, the decimator
+    // ranges a pair does not cover (the first segment of a stream is decimated whole,
+    // src/psd.rs:235-238; outputs still inside the drain; unaligned zero-copy spans) -- goes
+    // through the generic welch / hbf_dec8 kernels.  Both write the same partial slab and
+    // next-stage stream, so the reduce and the bookkeeping do not care which ran.
     struct PlanFused { FusedJob j; size_t work; };
     struct PlanSeg { SegJob j; size_t work; };
     std::vector<PlanFused> fjobs;
