@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=26, help="samples per channel per step = 2^this")
     ap.add_argument("--channels-per-gpu", type=int, default=1)
     ap.add_argument("--detrend", default="none")
+    ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--single-device", action="store_true",
@@ -128,6 +129,9 @@ def main():
     T = 1 << args.log2_batch
     bank = pkg.PsdCascadeBank(n, C, device=local_rank)
     bank.set_detrend(pkg.Detrend[args.detrend.upper()])
+    if args.avg:
+        lim, cnt = (int(v) for v in args.avg.split(","))
+        bank.set_avg(pkg.AvgOpts(lim, cnt))
     # synthetic raw-f32 streams, generated on the device: channel c of rank r uses seed 0x7654321 + global channel
     bufs = []
     for c in range(C):
