@@ -272,10 +272,14 @@ bool window_consts(uint32_t n, int kind, WindowConsts *w)
 
 bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1)) == 0; }
 
-// PsdStage::gain (src/psd.rs:279-283): u32 multiply, then two f32 multiplies
+// PsdStage::gain (src/psd.rs:279-283): (N/2 * count) as f32, then two f32 multiplies.  The
+// reference forms the product in u32, which overflows (panic in debug builds, wrap-around in
+// release) once count > 2^32 / (N/2): 8.4 M segments at N = 1024 -- hours for the CPU path,
+// about ten seconds of continuous plain-sum ingest here.  The product is widened; below the
+// overflow the value is bit-identical to the reference's.
 float stage_gain(uint32_t n, uint32_t count, float nenbw, float power)
 {
-    const uint32_t m = n / 2u * count; // wraps like release-mode Rust
+    const uint64_t m = (uint64_t)(n / 2u) * count;
     return (float)m * nenbw * power;
 }
 

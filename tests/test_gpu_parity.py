@@ -481,6 +481,31 @@ def test_cpp_mirror_stream_test_flow(pkg, gpu_required):
     assert "0 out of bound, Linear throws" in r.stdout, r.stdout[-2000:]
 
 
+def test_past_the_u32_gain_overflow(pkg, gpu_required):
+    """2^32 samples and more: the reference's gain() forms N/2 * count in u32 (src/psd.rs:282), which
+    overflows there (debug: panic, release: wrap) -- reached in seconds at this rate.  The library
+    widens the product: the PSD of unit-variance white noise must still read 2."""
+    import torch
+    n, total, reps = 1024, 1 << 26, 66
+    d = torch.empty(total, dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), total, seed=4242)
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 1)
+    for _ in range(reps):
+        g.process_device(0, d.data_ptr(), total)
+    info = g.stage_info(0, 0)
+    assert info["count"] * (n // 2) > 2 ** 32  # past the reference's overflow
+    assert info["count"] == 1 + (reps * total - n) // (n // 2)
+    gain = g.stage_gain(0, 0)
+    assert gain == pytest.approx(float(info["count"]) * (n // 2) * 0.375, rel=1e-6)
+    p = g.stage_spectrum(0, 0) / gain
+    # the same 2^26 samples 66 times over: each bin is an average over the 131072 distinct segments
+    assert np.all(np.abs(p[1:-1] * 0.5 - 1.0) < 10.0 / np.sqrt(131072.0))
+    psd, br = g.psd(0)
+    assert np.all(np.isfinite(psd)) and abs(float(np.mean(psd[br[-1].start + 1:-1])) * 0.5 - 1.0) < 1e-3
+    g.close()
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch
