@@ -225,11 +225,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         if constexpr (DETREND == 3) { // Mean in two steps: o = f32 mean of the samples, m = mean of x - o
             // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
             auto block_sum2 = [&](float &pa, float &pb) { // both sums over the workgroup, same value in every thread
-#pragma unroll
-                for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                    pa += __shfl_xor(pa, o2, 64);
-                    pb += __shfl_xor(pb, o2, 64);
-                }
+                pa = wave_sum64(pa);
+                pb = wave_sum64(pb);
                 if ((tp & 63) == 0) {
                     s_red[4 + 2 * (tp >> 6)] = pa;
                     s_red[5 + 2 * (tp >> 6)] = pb;

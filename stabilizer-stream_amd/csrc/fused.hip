@@ -65,30 +65,16 @@ __device__ __forceinline__ float team_bcast(float v, int team_lane0, int tl)
         return __shfl(v, team_lane0 + tl, 64);
 }
 
-// sum over the lanes of a team, the same value in every lane.  Rows of 16 lanes are reduced with
-// DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: plain VALU); only what crosses rows
-// goes through a shuffle (32 lanes) or scalar reads (64 lanes).  __shfl_xor would be six dependent
-// ds_bpermute round trips per sum.
+// sum over the lanes of a team, the same value in every lane (row_sum16 / wave_sum64 of
+// fused_common.h; only the 32-lane team needs one shuffle to join its two rows)
 template <int TEAM>
 __device__ __forceinline__ float team_sum(float v)
 {
-#define PSDK_DPP(x, ctrl) \
-    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
-    v += PSDK_DPP(v, 0xB1);  // quad_perm [1,0,3,2]
-    v += PSDK_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
-    v += PSDK_DPP(v, 0x141); // row_half_mirror
-    v += PSDK_DPP(v, 0x140); // row_mirror: every lane of a row holds the row's sum
-#undef PSDK_DPP
-    if constexpr (TEAM == 32) {
+    if constexpr (TEAM == 64)
+        return wave_sum64(v);
+    v = row_sum16(v);
+    if constexpr (TEAM == 32)
         v += __shfl_xor(v, 16, 64);
-    } else if constexpr (TEAM == 64) {
-        const int b = __builtin_bit_cast(int, v);
-        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
-        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
-        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-        v = (r0 + r1) + (r2 + r3);
-    }
     return v;
 }
 

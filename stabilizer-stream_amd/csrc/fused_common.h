@@ -80,6 +80,30 @@ __device__ __forceinline__ float dpp_ror1(float v)
                               __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
 }
 
+// Sum over a row of 16 lanes with DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: plain
+// VALU), every lane of the row receiving the row's sum; and over the wavefront (the four row sums
+// through scalar reads).  A __shfl_xor butterfly would be six dependent ds_bpermute round trips.
+__device__ __forceinline__ float row_sum16(float v)
+{
+#define PSDK_DPP(x, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
+    v += PSDK_DPP(v, 0xB1);  // quad_perm [1,0,3,2]
+    v += PSDK_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
+    v += PSDK_DPP(v, 0x141); // row_half_mirror
+    v += PSDK_DPP(v, 0x140); // row_mirror
+#undef PSDK_DPP
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v)
+{
+    const int b = __builtin_bit_cast(int, row_sum16(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 struct f2 {
     float x, y;
 };
