@@ -3,9 +3,10 @@
 
 namespace psdk {
 
-hipError_t launch_bigfused_16384(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
+hipError_t launch_bigfused_16384(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s,
+                                 hipEvent_t ea, hipEvent_t eb)
 {
-    return launch_bigfused_n<16384>(b, win, tw0g, twag, s);
+    return launch_bigfused_n<16384>(b, win, tw0g, twag, s, ea, eb);
 }
 
 } // namespace psdk

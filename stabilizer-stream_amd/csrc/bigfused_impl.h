@@ -8,6 +8,8 @@
 // threads would be capped at 128 VGPRs (16 wavefronts on one CU) and spilled ~450 bytes per lane.
 // Each bigfused_<N>.hip instantiates one size.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "fft_block.h"
 #include "fused_common.h"
 
@@ -390,15 +392,16 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 }
 
 template <int N>
-hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
+hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s,
+                             hipEvent_t ea, hipEvent_t eb)
 {
     const dim3 grid(b.nblocks), block(BigGeo<N>::THREADS);
 #define PSDK_BIG_CASE(D)                                                                          \
     case D:                                                                                       \
         if (b.any_ewma)                                                                           \
-            hipLaunchKernelGGL((bigfused_kernel<N, D, true>), grid, block, 0, s, b, win, tw0g, twag);  \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
         else                                                                                      \
-            hipLaunchKernelGGL((bigfused_kernel<N, D, false>), grid, block, 0, s, b, win, tw0g, twag); \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
         break;
     switch (b.detrend) {
         PSDK_BIG_CASE(0)

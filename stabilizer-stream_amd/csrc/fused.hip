@@ -20,6 +20,8 @@
 #include <cmath>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "fft_block.h"
 #include "fft_team.h"
 #include "fused_common.h"
@@ -567,16 +569,16 @@ void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa)
 }
 
 template <int N>
-static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s)
+static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     static_assert(FusedGeo<N>::LDS_BYTES <= 81920, "two workgroups per CU need <= 80 KiB of LDS each");
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
 #define PSDK_FUSED_CASE(D)                                                                \
     case D:                                                                               \
         if (b.any_ewma)                                                                   \
-            hipLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, b, win);     \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
         else                                                                              \
-            hipLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, b, win);    \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win); \
         break;
     switch (b.detrend) {
         PSDK_FUSED_CASE(0)
@@ -590,30 +592,31 @@ static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_bigfused_2048(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
-hipError_t launch_bigfused_4096(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
-hipError_t launch_bigfused_8192(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
-hipError_t launch_bigfused_16384(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t);
+hipError_t launch_bigfused_2048(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
+hipError_t launch_bigfused_4096(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
+hipError_t launch_bigfused_8192(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
+hipError_t launch_bigfused_16384(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
 
-hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s)
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s,
+                        hipEvent_t ea, hipEvent_t eb)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
     switch (n) {
     case 256:
-        return launch_fused_n<256>(b, win, s);
+        return launch_fused_n<256>(b, win, s, ea, eb);
     case 512:
-        return launch_fused_n<512>(b, win, s);
+        return launch_fused_n<512>(b, win, s, ea, eb);
     case 1024:
-        return launch_fused_n<1024>(b, win, s);
+        return launch_fused_n<1024>(b, win, s, ea, eb);
     case 2048:
-        return launch_bigfused_2048(b, win, tw0g, twag, s);
+        return launch_bigfused_2048(b, win, tw0g, twag, s, ea, eb);
     case 4096:
-        return launch_bigfused_4096(b, win, tw0g, twag, s);
+        return launch_bigfused_4096(b, win, tw0g, twag, s, ea, eb);
     case 8192:
-        return launch_bigfused_8192(b, win, tw0g, twag, s);
+        return launch_bigfused_8192(b, win, tw0g, twag, s, ea, eb);
     case 16384:
-        return launch_bigfused_16384(b, win, tw0g, twag, s);
+        return launch_bigfused_16384(b, win, tw0g, twag, s, ea, eb);
     default:
         return hipErrorInvalidValue;
     }

@@ -140,8 +140,10 @@ int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
 int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
 // twiddle tables in global memory for the workgroup-level kernels (N >= 2048); empty otherwise
 void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa);
+// ev_a / ev_b (both or neither): events that receive the kernel's own start and stop times
+// (hipExtLaunchKernelGGL), for PSDC_OPT_PROFILE
 hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag,
-                        hipStream_t s);
+                        hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);

@@ -728,20 +728,25 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     }
 
     // ---- launches: fused, generic welch, reduce, generic decimator -------
-    // HIP events bracket the dominant kernel of the round (fused when present)
+    // HIP events time the dominant kernel of the round (fused when present).  The fused launches
+    // hand their events to hipExtLaunchKernelGGL, which stamps the kernel's own start and stop (what
+    // rocprofv3 --kernel-trace reports); events recorded around a launch would include the ~6 us
+    // dependent-dispatch gap in front of it.  The generic welch kernel keeps the bracket.
     const bool prof_fused = fast_ok; // the handle's dominant kernel kind, not the round's
-    auto prof_begin = [&](ProfEvents &pe) -> int {
+    auto prof_begin = [&](ProfEvents &pe, bool record) -> int {
         if (!h->profile)
             return PSDC_OK;
         HIPCHK(h, hipEventCreate(&pe.a));
         HIPCHK(h, hipEventCreate(&pe.b));
-        HIPCHK(h, hipEventRecord(pe.a, h->stream));
+        if (record)
+            HIPCHK(h, hipEventRecord(pe.a, h->stream));
         return PSDC_OK;
     };
-    auto prof_end = [&](ProfEvents &pe, bool first) -> int {
+    auto prof_end = [&](ProfEvents &pe, bool first, bool record) -> int {
         if (!h->profile)
             return PSDC_OK;
-        HIPCHK(h, hipEventRecord(pe.b, h->stream));
+        if (record)
+            HIPCHK(h, hipEventRecord(pe.b, h->stream));
         h->prof_pending.push_back(pe);
         h->prof.launches += 1;
         if (first) {
@@ -762,10 +767,10 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         }
         ProfEvents pe{};
         const bool first = (i <= (size_t)MAX_JOBS);
-        if ((rc = prof_begin(pe)))
+        if ((rc = prof_begin(pe, false)))
             return rc;
-        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->stream));
-        if ((rc = prof_end(pe, first)))
+        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->stream, pe.a, pe.b));
+        if ((rc = prof_end(pe, first, false)))
             return rc;
     }
     for (size_t i = 0; i < sjobs.size();) {
@@ -780,10 +785,10 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         }
         ProfEvents pe{};
         const bool first = (i <= (size_t)MAX_JOBS);
-        if (!prof_fused && (rc = prof_begin(pe)))
+        if (!prof_fused && (rc = prof_begin(pe, true)))
             return rc;
         HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
-        if (!prof_fused && (rc = prof_end(pe, first)))
+        if (!prof_fused && (rc = prof_end(pe, first, true)))
             return rc;
     }
     for (size_t i = 0; i < djobs.size();) {
