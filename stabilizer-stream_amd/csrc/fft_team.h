@@ -44,7 +44,7 @@ struct TeamFft {
         for (int c = 0; c < 4; ++c) {
             cf b[4] = {v[c], v[4 + c], v[8 + c], v[12 + c]};
             Dft<4>::run(b);
-            const cf w1 = lds_ld(tw0 + c * TEAM + tl);
+            const cf w1 = tw0[c * TEAM + tl]; // (plain loads: see pass1)
             const cf w2 = cmul(w1, w1);
             const cf w3 = cmul(w2, w1);
             v[c] = b[0];
@@ -89,7 +89,11 @@ struct TeamFft {
             Dft<R1>::run(v + R1 * i);
 #pragma unroll
             for (int q = 1; q < R1; ++q)
-                v[R1 * i + q] = cmul(v[R1 * i + q], lds_ld(tw1 + (q - 1) * 16 + s));
+                // plain (not lds_ld) loads: kept single, the R1 - 1 twiddle reads ended up serialised
+                // through one register pair -- a chain of LDS round trips; left to the compiler they pair
+                // up as ds_read2_b64 (dearer per byte) but are all in flight together: +2.5 % at N = 1024,
+                // +13 % at N = 256
+                v[R1 * i + q] = cmul(v[R1 * i + q], tw1[(q - 1) * 16 + s]);
         }
     }
     static PSDK_HD void store1(int tl, const cf *v, cf *frame)
