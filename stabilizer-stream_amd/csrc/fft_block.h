@@ -123,7 +123,9 @@ struct BlockFft {
             Dft<RB>::run(v + RB * i);
 #pragma unroll
             for (int q = 1; q < RB; ++q)
-                v[RB * i + q] = cmul(v[RB * i + q], lds_ld(twb + (q - 1) * 16 + s));
+                // plain loads as in fft_team.h pass1 (+3-5 %); N = 16384 has no registers to keep them
+                // in flight (two lanes per thread) and stays with the single reads
+                v[RB * i + q] = cmul(v[RB * i + q], N >= 16384 ? lds_ld(twb + (q - 1) * 16 + s) : twb[(q - 1) * 16 + s]);
         }
     }
     static PSDK_HD void storeB(int tl, const cf *v, cf *frame)
