@@ -197,8 +197,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             hs[tp] = sf[h_pack >> 16];
 
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
-        float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
-        slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+        DetrendParams dp;
+        float &oa = dp.oa, &ob = dp.ob, &ma = dp.ma, &mb = dp.mb;
+        slope2 &sa = dp.sa, &sb = dp.sb;
         if constexpr (DETREND == 1) { // the segments' midpoint samples (lane 0)
             if (tp == 0) {
                 s_red[0] = up[0][0].x;
@@ -269,56 +270,18 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 
         // ---- FFT of the pair ---------------------------------------------------------------
         cf vv[VT][16];
-        float ea = 1.0f, eb = 1.0f;
         if constexpr (EWMA) {
             if (job.ewma) {
-                ea = fused_ewma_amp(job, job.step0 + 2 * p);
-                eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                dp.ea = fused_ewma_amp(job, job.step0 + 2 * p);
+                dp.eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
             }
         }
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
-            const float nf = (float)(4 * tl);
-            auto put = [&](int slot, float xa, float xb, float w, int nofs) {
-                if constexpr (DETREND == 1) {
-                    xa -= oa;
-                    xb -= ob;
-                } else if constexpr (DETREND == 2) {
-                    const float n = nf + (float)nofs;
-                    xa = fmaf(-n, sa.lo, fmaf(-n, sa.hi, xa - oa));
-                    xb = fmaf(-n, sb.lo, fmaf(-n, sb.hi, xb - ob));
-                } else if constexpr (DETREND == 3) {
-                    xa = (xa - oa) - ma;
-                    xb = (xb - ob) - mb;
-                }
-                xa *= w;
-                xb *= w;
-                if constexpr (EWMA) {
-                    xa *= ea;
-                    xb *= eb;
-                }
-                vv[v][slot] = {xa, xb};
-            };
             const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
-            const float4 w0 = wp[0], w1 = wp[TEAM], w2 = wp[2 * TEAM], w3 = wp[3 * TEAM];
-            const float4 a0 = lo[v][0], a1 = lo[v][1], a2 = up[v][0], a3 = up[v][1], b2 = nl[v][0], b3 = nl[v][1];
-            put(0, a0.x, a2.x, w0.x, 0);
-            put(1, a0.y, a2.y, w0.y, 1);
-            put(2, a0.z, a2.z, w0.z, 2);
-            put(3, a0.w, a2.w, w0.w, 3);
-            put(4, a1.x, a3.x, w1.x, N / 4);
-            put(5, a1.y, a3.y, w1.y, N / 4 + 1);
-            put(6, a1.z, a3.z, w1.z, N / 4 + 2);
-            put(7, a1.w, a3.w, w1.w, N / 4 + 3);
-            put(8, a2.x, b2.x, w2.x, N / 2);
-            put(9, a2.y, b2.y, w2.y, N / 2 + 1);
-            put(10, a2.z, b2.z, w2.z, N / 2 + 2);
-            put(11, a2.w, b2.w, w2.w, N / 2 + 3);
-            put(12, a3.x, b3.x, w3.x, 3 * N / 4);
-            put(13, a3.y, b3.y, w3.y, 3 * N / 4 + 1);
-            put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
-            put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
+            window_pair<N, DETREND, EWMA>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wp[0],
+                                          wp[TEAM], wp[2 * TEAM], wp[3 * TEAM], dp);
             // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
             // go one after the other between two barriers)
             T::pass0(tl, vv[v], tw0p);

@@ -324,8 +324,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
             // segment a = (lo, up), segment b = (up, nl).  The trend is removed as
             // (x - o) - (m + n s): o is a sample of the segment (exact difference), the remainder is
             // small, so a DC level far above the noise does not cost the result its low bits.
-            float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
-            slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+            DetrendParams dp;
+            float &oa = dp.oa, &ob = dp.ob, &ma = dp.ma, &mb = dp.mb;
+            slope2 &sa = dp.sa, &sb = dp.sb;
             const int l0 = lane - tl; // first lane of this team
             if constexpr (DETREND == 1) { // Midpoint: x[N/2] (src/psd.rs:87-93)
                 oa = team_bcast<TEAM>(up[0].x, l0, 0);
@@ -353,52 +354,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
                 ma = team_sum<TEAM>(sl + sua) * (1.0f / (float)N);
                 mb = team_sum<TEAM>(sub + sn) * (1.0f / (float)N);
             }
-            float ea = 1.0f, eb = 1.0f;
             if constexpr (EWMA) {
                 if (job.ewma) {
-                    ea = fused_ewma_amp(job, job.step0 + 2 * p);
-                    eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                    dp.ea = fused_ewma_amp(job, job.step0 + 2 * p);
+                    dp.eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
                 }
             }
-            const float nf = (float)(4 * tl);
-            auto put = [&](int slot, float xa, float xb, float w, int nofs) {
-                if constexpr (DETREND == 1) {
-                    xa -= oa;
-                    xb -= ob;
-                } else if constexpr (DETREND == 2) {
-                    const float n = nf + (float)nofs;
-                    xa = fmaf(-n, sa.lo, fmaf(-n, sa.hi, xa - oa));
-                    xb = fmaf(-n, sb.lo, fmaf(-n, sb.hi, xb - ob));
-                } else if constexpr (DETREND == 3) {
-                    xa = (xa - oa) - ma;
-                    xb = (xb - ob) - mb;
-                }
-                xa *= w;
-                xb *= w;
-                if constexpr (EWMA) {
-                    xa *= ea;
-                    xb *= eb;
-                }
-                v[slot] = {xa, xb};
-            };
-            const float4 w0 = s_win[tl], w1 = s_win[TEAM + tl], w2 = s_win[2 * TEAM + tl], w3 = s_win[3 * TEAM + tl];
-            const float4 a0 = lo[0], a1 = lo[1], a2 = up[0], a3 = up[1], b2 = nl[0], b3 = nl[1];
-            put(0, a0.x, a2.x, w0.x, 0);
-            put(1, a0.y, a2.y, w0.y, 1);
-            put(2, a0.z, a2.z, w0.z, 2);
-            put(3, a0.w, a2.w, w0.w, 3);
-            put(4, a1.x, a3.x, w1.x, N / 4);
-            put(5, a1.y, a3.y, w1.y, N / 4 + 1);
-            put(6, a1.z, a3.z, w1.z, N / 4 + 2);
-            put(7, a1.w, a3.w, w1.w, N / 4 + 3);
-            put(8, a2.x, b2.x, w2.x, N / 2);
-            put(9, a2.y, b2.y, w2.y, N / 2 + 1);
-            put(10, a2.z, b2.z, w2.z, N / 2 + 2);
-            put(11, a2.w, b2.w, w2.w, N / 2 + 3);
-            put(12, a3.x, b3.x, w3.x, 3 * N / 4);
-            put(13, a3.y, b3.y, w3.y, 3 * N / 4 + 1);
-            put(14, a3.z, b3.z, w3.z, 3 * N / 4 + 2);
-            put(15, a3.w, b3.w, w3.w, 3 * N / 4 + 3);
+            window_pair<N, DETREND, EWMA>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
+                                          s_win[2 * TEAM + tl], s_win[3 * TEAM + tl], dp);
         }
         { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT.  Issued
           // unconditionally (after the last pair: re-reads, unused) -- a load under a branch is

@@ -161,4 +161,57 @@ __device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
     return (float)exp2(0.5 * (double)na * job.log2_gamma);
 }
 
+// Detrend + window + EWMA amplitude of one segment pair into the 16 FFT inputs of a lane
+// (src/psd.rs:75-113, :211): lane tl holds samples 4 tl + c + (N/4) m of segment a in (lo0, lo1, up0,
+// up1)[m].c and of segment b in (up0, up1, nl0, nl1)[m].c; slot 4m + c gets
+// {(xa - trend_a) w, (xb - trend_b) w}.  The trend is removed as (x - o) - (m + n s): see DESIGN.md.
+struct DetrendParams {
+    float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
+    slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+    float ea = 1.0f, eb = 1.0f; // EWMA amplitudes
+};
+template <int N, int DETREND, bool EWMA>
+__device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &lo0, const float4 &lo1, const float4 &up0,
+                                            const float4 &up1, const float4 &nl0, const float4 &nl1, const float4 &w0,
+                                            const float4 &w1, const float4 &w2, const float4 &w3, const DetrendParams &d)
+{
+    const float nf = (float)(4 * tl);
+    auto put = [&](int slot, float xa, float xb, float w, int nofs) {
+        if constexpr (DETREND == 1) {
+            xa -= d.oa;
+            xb -= d.ob;
+        } else if constexpr (DETREND == 2) {
+            const float n = nf + (float)nofs;
+            xa = fmaf(-n, d.sa.lo, fmaf(-n, d.sa.hi, xa - d.oa));
+            xb = fmaf(-n, d.sb.lo, fmaf(-n, d.sb.hi, xb - d.ob));
+        } else if constexpr (DETREND == 3) {
+            xa = (xa - d.oa) - d.ma;
+            xb = (xb - d.ob) - d.mb;
+        }
+        xa *= w;
+        xb *= w;
+        if constexpr (EWMA) {
+            xa *= d.ea;
+            xb *= d.eb;
+        }
+        v[slot] = {xa, xb};
+    };
+    put(0, lo0.x, up0.x, w0.x, 0);
+    put(1, lo0.y, up0.y, w0.y, 1);
+    put(2, lo0.z, up0.z, w0.z, 2);
+    put(3, lo0.w, up0.w, w0.w, 3);
+    put(4, lo1.x, up1.x, w1.x, N / 4);
+    put(5, lo1.y, up1.y, w1.y, N / 4 + 1);
+    put(6, lo1.z, up1.z, w1.z, N / 4 + 2);
+    put(7, lo1.w, up1.w, w1.w, N / 4 + 3);
+    put(8, up0.x, nl0.x, w2.x, N / 2);
+    put(9, up0.y, nl0.y, w2.y, N / 2 + 1);
+    put(10, up0.z, nl0.z, w2.z, N / 2 + 2);
+    put(11, up0.w, nl0.w, w2.w, N / 2 + 3);
+    put(12, up1.x, nl1.x, w3.x, 3 * N / 4);
+    put(13, up1.y, nl1.y, w3.y, 3 * N / 4 + 1);
+    put(14, up1.z, nl1.z, w3.z, 3 * N / 4 + 2);
+    put(15, up1.w, nl1.w, w3.w, 3 * N / 4 + 3);
+}
+
 } // namespace psdk
