@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=26, help="samples per channel per step = 2^this")
     ap.add_argument("--channels-per-gpu", type=int, default=1)
     ap.add_argument("--detrend", default="none")
+    ap.add_argument("--coalesce", type=int, default=None,
+                    help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 4)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
@@ -129,6 +131,8 @@ def main():
     T = 1 << args.log2_batch
     bank = pkg.PsdCascadeBank(n, C, device=local_rank)
     bank.set_detrend(pkg.Detrend[args.detrend.upper()])
+    if args.coalesce is not None:
+        bank.configure(coalesce=args.coalesce)
     if args.avg:
         lim, cnt = (int(v) for v in args.avg.split(","))
         bank.set_avg(pkg.AvgOpts(lim, cnt))

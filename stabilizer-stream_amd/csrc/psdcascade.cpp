@@ -67,8 +67,11 @@ struct Channel {
     int cur_stage = 0;
     size_t fill = 0;
     bool submitted = false; // device holds samples that advance() has not looked at yet
-    bool has_span = false;  // zero-copy span registered but not enqueued
-    DeviceSpan span;
+    // zero-copy spans registered but not enqueued yet, in stream order.  More than one is held
+    // while the device is still busy with earlier rounds (PSDC_OPT_COALESCE): they go out as ONE
+    // round, which halves / quarters the per-round launch overhead per sample.
+    std::vector<DeviceSpan> spans;
+    bool has_span() const { return !spans.empty(); }
 };
 
 struct ProfEvents {
@@ -110,6 +113,8 @@ struct psdc_handle {
     size_t frames_cap = 0; // bytes per buffer
     int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
+    uint32_t coalesce = 4; // zero-copy spans per channel held back while the device is busy (1 = none)
+    bool coalesce_always = false; // hold them back even when the device is idle (tests)
     bool profile = false;
     std::vector<ProfEvents> prof_pending;
     psdc_profile prof{};
@@ -383,12 +388,13 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
     return PSDC_OK;
 }
 
-// both ping-pong buffers can hold `need` floats (content of the current one is kept)
-int ensure_cap(psdc_handle *h, StageState &s, size_t need)
+// both ping-pong buffers can hold `need` floats (content of the current one is kept); when they have
+// to grow they grow to `grow_to` (>= need) at once -- a re-allocation synchronises the stream
+int ensure_cap(psdc_handle *h, StageState &s, size_t need, size_t grow_to = 0)
 {
     if (need <= s.buf.cap)
         return PSDC_OK;
-    return ensure_room(h, s, s.buf.base + need);
+    return ensure_room(h, s, s.buf.base + std::max(need, grow_to));
 }
 
 int ensure_partial(psdc_handle *h, size_t floats)
@@ -409,18 +415,22 @@ int ensure_partial(psdc_handle *h, size_t floats)
     return PSDC_OK;
 }
 
+constexpr int MAX_COALESCE = 8; // zero-copy spans of one channel in one round
+
 struct Span { // one contiguous source of a (channel, stage) batch
     const float *src;
     uint64_t src_base;
     uint64_t seg_a, seg_b; // segments [seg_a, seg_b)
     uint64_t m_a, m_b;     // decimator outputs [m_a, m_b)
+    bool fixed = false;    // src is not the start of the stage's stream buffer (caller memory or a
+                           // seam region inside the buffer): leave it alone when buffers are re-based
 };
 
 struct Work {
     uint32_t c, k;
     uint64_t j_old, j_new, p_old, p_new;
     EwmaPlan ew;
-    Span spans[2];
+    Span spans[2 * MAX_COALESCE];
     int nspans = 0;
 };
 
@@ -437,6 +447,9 @@ int collect_profile(psdc_handle *h)
     h->prof_pending.clear();
     return PSDC_OK;
 }
+
+// nothing of this handle is executing or queued on the device
+bool device_idle(psdc_handle *h) { return !h->coalesce_always && hipStreamQuery(h->stream) == hipSuccess; }
 
 // One round of the cascade pipeline: every (channel, stage) that has complete
 // segments in its stream buffer is issued, all stages in the SAME launches.
@@ -464,19 +477,50 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
     // the carried tail) behind the tail; the bulk is read in place.  One copy
-    // launch for all channels.
+    // launch for all channels.  A channel may hold several spans (PSDC_OPT_COALESCE): each
+    // further span gets a seam REGION of its own in the stream buffer, behind the contiguous
+    // part -- the tail the span before it would have carried (read from that span's end) followed
+    // by the head of the span -- so that the segments straddling two spans see contiguous memory.
+    struct Region { // seam region of span i >= 1 of a channel
+        size_t off;      // floats from the start of the stream buffer
+        uint64_t base;   // absolute index of its first sample (the keep_from point after span i-1)
+    };
+    std::vector<std::vector<Region>> regions(h->n_channels);
     {
         std::vector<TailJob> seams;
-        for (auto &c : h->ch) {
-            if (!c.has_span)
+        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+            Channel &c = h->ch[ci];
+            if (!c.has_span())
                 continue;
             StageState &s0 = c.st[0];
-            const uint64_t cp = std::min<uint64_t>(seam, c.span.len);
-            int rc = ensure_room(h, s0, c.span.first + cp);
+            const size_t ns = c.spans.size();
+            // contiguous part: the carried tail + the seam of the first span
+            const uint64_t cp0 = std::min<uint64_t>(seam, c.spans[0].len);
+            size_t need = (size_t)(c.spans[0].first + cp0 - s0.buf.base);
+            regions[ci].resize(ns);
+            for (size_t i = 1; i < ns; ++i) {
+                StageState t; // the stage as it stands once span i-1 is consumed
+                t.segs = segments_for(g, c.spans[i].first);
+                t.dec = decimated_prefix(g, t.segs);
+                const uint64_t kf = keep_from(g, t);
+                if (kf < c.spans[i - 1].first)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: coalesced span shorter than the carried tail");
+                regions[ci][i] = {need, kf};
+                need += (size_t)(c.spans[i].first - kf) + (size_t)std::min<uint64_t>(seam, c.spans[i].len);
+            }
+            int rc = ensure_room(h, s0, s0.buf.base + need);
             if (rc)
                 return rc;
-            seams.push_back({c.span.d_x, s0.buf.p[s0.buf.cur] + (c.span.first - s0.buf.base), (int)cp});
-            s0.buf.end = c.span.first + cp;
+            float *buf = s0.buf.p[s0.buf.cur];
+            seams.push_back({c.spans[0].d_x, buf + (c.spans[0].first - s0.buf.base), (int)cp0});
+            s0.buf.end = c.spans[0].first + cp0;
+            for (size_t i = 1; i < ns; ++i) {
+                const Region &r = regions[ci][i];
+                const DeviceSpan &pv = c.spans[i - 1], &sp = c.spans[i];
+                const size_t back = (size_t)(sp.first - r.base);
+                seams.push_back({pv.d_x + (r.base - pv.first), buf + r.off, (int)back});
+                seams.push_back({sp.d_x, buf + r.off + back, (int)std::min<uint64_t>(seam, sp.len)});
+            }
         }
         int rc = launch_deferred(h, seams); // with the last round's epilogue
         if (rc)
@@ -506,36 +550,53 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             w.p_new = decimated_prefix(g, j_new);
             w.ew = plan_ewma(s.count, cur_stage_avg(h, k), j_new - s.segs);
             const uint64_t m_old = w.p_old >> 3, m_new = w.p_new >> 3;
-            if (k == 0 && c.has_span) {
-                const uint64_t first = c.span.first;
-                uint64_t j_split =
-                    std::min<uint64_t>(j_new, std::max<uint64_t>(w.j_old, (first + g.hop - 1) / g.hop));
-                uint64_t m_split =
-                    std::min<uint64_t>(m_new, std::max<uint64_t>(m_old, (first + HBF_HALO + 7) / 8));
-                if (fast_ok && w.j_old > 0) {
-                    // fast path: the tail side gets a whole number of segment pairs and exactly their
-                    // decimator outputs; the in-place side starts >= need_pre samples into the span
-                    uint64_t js = std::max<uint64_t>(w.j_old, (first + need_pre + g.hop - 1) / g.hop);
-                    if ((js - w.j_old) & 1)
-                        js += 1;
-                    if (js < j_new && (js + 1) * g.hop <= first + seam && c.span.len >= seam) {
-                        j_split = js;
-                        m_split = std::min<uint64_t>(m_new, (js + 1) * (g.hop / 8));
+            if (k == 0 && c.has_span()) {
+                // span by span, each exactly as a round of its own would split it: the buffer side
+                // (carried tail + seam: contiguous part for the first span, its seam region for the
+                // others) and the in-place side
+                uint64_t j_lo = w.j_old, m_lo = m_old;
+                const size_t ns = c.spans.size();
+                for (size_t i = 0; i < ns; ++i) {
+                    const DeviceSpan &sp = c.spans[i];
+                    const uint64_t first = sp.first;
+                    const uint64_t j_hi = i + 1 < ns ? segments_for(g, c.spans[i + 1].first) : j_new;
+                    const uint64_t m_hi = i + 1 < ns ? decimated_prefix(g, j_hi) >> 3 : m_new;
+                    uint64_t j_split =
+                        std::min<uint64_t>(j_hi, std::max<uint64_t>(j_lo, (first + g.hop - 1) / g.hop));
+                    uint64_t m_split =
+                        std::min<uint64_t>(m_hi, std::max<uint64_t>(m_lo, (first + HBF_HALO + 7) / 8));
+                    if (fast_ok && j_lo > 0) {
+                        // fast path: the tail side gets a whole number of segment pairs and exactly their
+                        // decimator outputs; the in-place side starts >= need_pre samples into the span
+                        uint64_t js = std::max<uint64_t>(j_lo, (first + need_pre + g.hop - 1) / g.hop);
+                        if ((js - j_lo) & 1)
+                            js += 1;
+                        if (js < j_hi && (js + 1) * g.hop <= first + seam && sp.len >= seam) {
+                            j_split = js;
+                            m_split = std::min<uint64_t>(m_hi, (js + 1) * (g.hop / 8));
+                        }
                     }
+                    if (j_split > j_lo || m_split > m_lo) {
+                        if (i == 0)
+                            w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, j_lo, j_split, m_lo, m_split, false};
+                        else
+                            w.spans[w.nspans++] = {s.buf.p[s.buf.cur] + regions[ci][i].off, regions[ci][i].base,
+                                                   j_lo, j_split, m_lo, m_split, true};
+                    }
+                    if (j_hi > j_split || m_hi > m_split)
+                        w.spans[w.nspans++] = {sp.d_x, first, j_split, j_hi, m_split, m_hi, true};
+                    j_lo = j_hi;
+                    m_lo = m_hi;
                 }
-                if (j_split > w.j_old || m_split > m_old)
-                    w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_split, m_old, m_split};
-                if (j_new > j_split || m_new > m_split)
-                    w.spans[w.nspans++] = {c.span.d_x, first, j_split, j_new, m_split, m_new};
             } else {
-                w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new};
+                w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new, false};
             }
             works.push_back(w);
         }
     }
     if (works.empty()) {
         for (auto &c : h->ch) {
-            if (c.has_span)
+            if (c.has_span())
                 return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
             c.submitted = false;
         }
@@ -564,7 +625,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                     return rc;
             }
             StageState &nx = c.st[w.k + 1];
-            int rc = ensure_cap(h, nx, (size_t)(t_next - kf_after(w.c, w.k + 1)));
+            // rounds hold 1 ... PSDC_OPT_COALESCE in-place spans: size the next stage's stream for the
+            // largest round the first time it has to grow, not round size by round size
+            const size_t need = (size_t)(t_next - kf_after(w.c, w.k + 1));
+            const size_t nsp = std::max<size_t>(1, c.spans.size());
+            int rc = ensure_cap(h, nx, need, c.has_span() ? need * h->coalesce / nsp + (size_t)4 * (h->n + HBF_HALO) : 0);
             if (rc)
                 return rc;
         }
@@ -573,7 +638,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     for (auto &w : works) {
         StageState &s = h->ch[w.c].st[w.k];
         for (int i = 0; i < w.nspans; ++i)
-            if (!(w.k == 0 && h->ch[w.c].has_span && w.spans[i].src == h->ch[w.c].span.d_x)) {
+            if (!w.spans[i].fixed) {
                 w.spans[i].src = s.buf.p[s.buf.cur];
                 w.spans[i].src_base = s.buf.base;
             }
@@ -685,15 +750,27 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     const uint64_t teams = (uint64_t)std::max(1, fused_pairs_per_block((int)h->n, 1));
     for (size_t b0 = 0; b0 < fjobs.size(); b0 += MAX_JOBS) {
         const size_t b1 = std::min(fjobs.size(), b0 + (size_t)MAX_JOBS);
+        // One run length R for the whole launch: the smallest R for which the jobs' workgroups
+        // (ceil(pairs / (R teams)) each) fit the resident capacity.  A launch that asks for more
+        // workgroups than are resident at once runs the surplus as a second wave behind the first.
+        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n);
         uint64_t pairs = 0;
         for (size_t i = b0; i < b1; ++i)
             pairs += (uint64_t)fjobs[i].j.npairs;
+        auto blocks_at = [&](uint64_t r) {
+            uint64_t nb = 0;
+            for (size_t i = b0; i < b1; ++i)
+                nb += ((uint64_t)fjobs[i].j.npairs + r * teams - 1) / (r * teams);
+            return nb;
+        };
+        uint64_t R = std::max<uint64_t>(1, (pairs + cap * teams - 1) / (cap * teams));
+        while (blocks_at(R) > cap)
+            ++R;
         for (size_t i = b0; i < b1; ++i) {
-            // workgroups in proportion to the pairs; every team of a job gets the same run
             FusedJob &j = fjobs[i].j;
             const uint64_t np = (uint64_t)j.npairs;
-            const uint64_t share = std::max<uint64_t>(1, (np * (uint64_t)fused_max_blocks((int)h->n) + pairs / 2) / pairs);
-            const uint64_t run = (np + share * teams - 1) / (share * teams);
+            const uint64_t nb = (np + R * teams - 1) / (R * teams);
+            const uint64_t run = (np + nb * teams - 1) / (nb * teams); // evened out within the job (<= R)
             j.run = (int)run;
             j.nblocks = (int)((np + run * teams - 1) / (run * teams));
             blocks_total += (size_t)j.nblocks;
@@ -832,11 +909,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             const bool received = s.total != told;
             if (kf == s.buf.base && !received && s.buf.end == s.total)
                 continue;
-            const bool span0 = (k == 0 && c.has_span);
+            const bool span0 = (k == 0 && c.has_span());
+            const DeviceSpan last = span0 ? c.spans.back() : DeviceSpan{};
             const uint64_t cnt = told > kf ? told - kf : 0;
             const float *src = nullptr;
-            if (span0 && kf >= c.span.first)
-                src = c.span.d_x + (kf - c.span.first);
+            if (span0 && kf >= last.first)
+                src = last.d_x + (kf - last.first);
             else if (span0)
                 return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
             else if (cnt)
@@ -855,7 +933,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     h->pend_red = std::move(rjobs);
     h->pend_tail = std::move(tjobs);
     for (auto &c : h->ch) {
-        c.has_span = false;
+        c.spans.clear();
         c.submitted = false;
     }
     return PSDC_OK;
@@ -1253,7 +1331,7 @@ int psdc_reset(psdc_handle *h)
         c.st.clear();
         c.fill = 0;
         c.submitted = false;
-        c.has_span = false;
+        c.spans.clear();
     }
     return PSDC_OK;
 }
@@ -1281,6 +1359,17 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
     case PSDC_OPT_PROFILE:
         h->profile = value != 0;
         return PSDC_OK;
+    case PSDC_OPT_COALESCE: {
+        const int64_t k = value < 0 ? -value : value; // negative: hold spans back even on an idle device
+        if (k < 1 || k > MAX_COALESCE)
+            return fail(h, PSDC_ERR_ARG, "coalesce out of range (1..8)");
+        int rc = flush_all(h);
+        if (rc)
+            return rc;
+        h->coalesce = (uint32_t)k;
+        h->coalesce_always = value < 0;
+        return PSDC_OK;
+    }
     default:
         return fail(h, PSDC_ERR_ARG, "unknown option");
     }
@@ -1325,7 +1414,7 @@ int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
     if (!x)
         return fail(h, PSDC_ERR_ARG, "null input");
     Channel &c = h->ch[channel];
-    if (c.has_span) { // keep the stream in order behind a pending zero-copy span
+    if (c.has_span()) { // keep the stream in order behind a pending zero-copy span
         rc = advance(h);
         if (rc)
             return rc;
@@ -1374,7 +1463,14 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
     if (!d_x)
         return fail(h, PSDC_ERR_ARG, "null input");
     Channel &c = h->ch[channel];
-    if (c.has_span || c.submitted) {
+    const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
+    // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
+    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them, and a device that is still
+    // busy with earlier rounds (when it is idle nothing is ever held back).
+    bool flush = c.submitted;
+    if (c.has_span() && (!in_place || c.fill > 0 || c.spans.size() >= h->coalesce || device_idle(h)))
+        flush = true;
+    if (flush) {
         rc = advance(h);
         if (rc)
             return rc;
@@ -1389,7 +1485,7 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
     }
     StageState &s0 = c.st[0];
     h->idle = false;
-    if (len < (size_t)4 * (h->n + HBF_HALO)) {
+    if (!in_place) {
         // short span: append a copy, like host-fed samples
         rc = ensure_room(h, s0, s0.total + len);
         if (rc)
@@ -1400,14 +1496,14 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
         s0.buf.end = s0.total;
         c.submitted = true;
     } else {
-        c.span.d_x = d_x;
-        c.span.first = s0.total;
-        c.span.len = len;
-        c.has_span = true;
+        c.spans.push_back({d_x, s0.total, len});
         s0.total += len;
     }
-    if (h->n_channels == 1)
+    if (h->n_channels == 1) {
+        if (c.has_span() && !c.submitted && c.spans.size() < h->coalesce && !device_idle(h))
+            return PSDC_OK; // the device is busy: the next span may share this one's round
         return advance(h);
+    }
     return PSDC_OK;
 }
 
@@ -1464,7 +1560,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
         // order behind anything pending on these channels
         bool pend = false;
         for (int ci = 0; ci < 4; ++ci)
-            pend = pend || h->ch[ci].has_span || h->ch[ci].submitted || h->ch[ci].fill;
+            pend = pend || h->ch[ci].has_span() || h->ch[ci].submitted || h->ch[ci].fill;
         if (pend) {
             rc = flush_all(h);
             if (rc)

@@ -40,6 +40,8 @@ for seed in range(first, first + count):
     torch.cuda.synchronize()
     try:
         g = pkg.PsdCascadeBank(n)
+        co = int(rng.choice([1, 4, -2, -3, -4, -8]))  # negative: spans are held back even on an idle device
+        g.configure(coalesce=co)
         g.set_detrend(pkg.Detrend[detrend.upper()])
         if avg:
             g.set_avg(pkg.AvgOpts(*avg))
@@ -53,10 +55,10 @@ for seed in range(first, first + count):
         g.sync()
         T.check_against_oracle(pkg, ora, g, chunks, n, detrend=detrend, avg=pkg.AvgOpts(*avg) if avg else None, what=f"seed {seed}")
         g.close()
-        print(f"seed {seed} n={n} {detrend} avg={avg} spans={lens} ofs={ofs} ok ({time.time() - t0:.0f}s)", flush=True)
+        print(f"seed {seed} n={n} {detrend} avg={avg} coalesce={co} spans={lens} ofs={ofs} ok ({time.time() - t0:.0f}s)", flush=True)
     except Exception:
         bad += 1
-        print(f"seed {seed} n={n} {detrend} avg={avg} spans={lens} ofs={ofs} FAILED", flush=True)
+        print(f"seed {seed} n={n} {detrend} avg={avg} coalesce={co} spans={lens} ofs={ofs} FAILED", flush=True)
         traceback.print_exc()
 print("failures:", bad)
 sys.exit(1 if bad else 0)
