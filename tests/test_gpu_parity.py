@@ -506,6 +506,34 @@ def test_past_the_u32_gain_overflow(pkg, gpu_required):
     g.close()
 
 
+@pytest.mark.parametrize("n,coalesce", [(1024, -2), (1024, -4), (1024, -8), (512, -3), (4096, -4), (1024, 4)])
+def test_coalesced_spans(pkg, ora, gpu_required, n, coalesce):
+    """PSDC_OPT_COALESCE: several in-place device spans of one channel go out as ONE round (each
+    with its own seam region between it and the span before).  Negative values hold spans back even
+    on an idle device, so the multi-span planner is exercised deterministically; a read-out in the
+    middle must flush whatever is held."""
+    import torch
+    lens = [40 * n + 4, 9 * n, 300 * n, 4 * (n + 288), 57 * n + 8, 120 * n, 33 * n + 12, 5 * n, 64 * n]
+    x = make_signal(pkg, sum(lens), seed=900 + n, tone=0.25)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 1)
+    g.configure(coalesce=coalesce)
+    chunks, a = [], 0
+    for i, m in enumerate(lens):
+        g.process_device(0, xd.data_ptr() + 4 * a, m)
+        chunks.append(x[a:a + m])
+        a += m
+        if i == 4:  # mid-stream read-out with spans pending
+            ref = ora.PsdCascade(n, "f64")
+            for c in chunks:
+                ref.process(c)
+            assert g.stage_info(0, 0) == ref.stage_info(0)
+    g.sync()
+    check_against_oracle(pkg, ora, g, chunks, n, what=f"coalesce {coalesce}")
+    g.close()
+
+
 def test_full_size_properties(pkg, gpu_required):
     """BASELINE config 2 size (2^26 samples, N=1024): size-independent properties."""
     import torch
