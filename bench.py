@@ -224,9 +224,14 @@ def main():
                        "stages": ns, "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                         "traffic_source": (tr["round"] + " PMC passes, profiles/") if tr else None,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * T * C,
+                         # launches hold 1..PSDC_OPT_COALESCE spans of 2^log2_batch samples: both per-launch
+                         # figures are for the AVERAGE launch of the timed region; the PMC traffic is measured
+                         # per one-span launch (--coalesce 1) and scaled by the spans per launch
+                         "traffic": (tr["hbm_bytes_per_launch"] * prof["stage0_samples"] / max(1, prof["launches"]) / (T * C)
+                                     if tr else None),
+                         "traffic_source": (tr["round"] + " PMC passes (one-span launches), profiles/") if tr else None,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / max(1, prof["launches"]),
+                         "spans_per_launch": prof["stage0_samples"] / max(1, prof["launches"]) / (T * C),
                          "kernel": kname, "launches": prof["launches"],
                          "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
                          "avg_launch_ms_whole_process": prof_all["kernel_ms"] / max(1, prof_all["launches"]),

@@ -17,7 +17,8 @@ rc=$?
 echo "stats rc=$rc"
 if [ $rc -ne 0 ]; then exit $rc; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$c.log 2>&1
+  # one span per launch here, so that a launch's traffic compares with 4 B x 2^26 samples
+  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --coalesce 1 --no-cpu-baseline > $out/bench_$c.log 2>&1
   rc=$?
   echo "$c rc=$rc"
   if [ $rc -ne 0 ]; then exit $rc; fi
