@@ -145,7 +145,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         const float *winp = win;
         if constexpr (VT > 1)
             asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
-        // ---- decimator ------------------------------------------------------------------
+        // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
+        if constexpr (VT == 1)
+            __builtin_amdgcn_s_setprio(3);
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
             sf[h_pack & 0xFFFFu] = hs[tp];
         // samples -> polyphase arrays as single floats (ds_write2_b32 from the registers the loads
@@ -195,6 +197,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         }
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
             hs[tp] = sf[h_pack >> 16];
+
+        if constexpr (VT == 1)
+            __builtin_amdgcn_s_setprio(0);
 
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
         DetrendParams dp;
