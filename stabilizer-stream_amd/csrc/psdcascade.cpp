@@ -88,6 +88,18 @@ struct psdc_handle {
     uint32_t n_channels = 0;
     int device = 0;
     hipStream_t stream = nullptr;
+    // Uploads (host-fed samples, frame blobs) run on a stream of their own so that the link works
+    // while the kernels of the previous piece run; `ev_upload` marks the last upload enqueued, and
+    // the compute stream waits for it before it touches anything (wait_uploads()).
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_upload = nullptr;
+    bool upload_pending = false;
+    // An upload lands in the stage-0 buffer that the round BEFORE the latest one read (ping-pong),
+    // whose end region is also the source of that round's tail carry -- which is deferred into the
+    // latest round's post launch.  So an upload may overlap the latest round's fused kernel but must
+    // wait for its post launch: ev_post is recorded right behind it.
+    hipEvent_t ev_post = nullptr;
+    bool post_marked = false;
     float *d_win = nullptr;
     cf *d_tw = nullptr;
     cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels
@@ -109,6 +121,8 @@ struct psdc_handle {
     uint8_t *d_frames[2] = {nullptr, nullptr};
     uint8_t *h_frames[2] = {nullptr, nullptr};
     hipEvent_t frames_ev[2] = {nullptr, nullptr}; // H2D of the buffer finished
+    hipEvent_t frames_dec_ev[2] = {nullptr, nullptr}; // the decode kernel has read the device image
+    bool frames_dec_pending[2] = {false, false};
     bool frames_ev_pending[2] = {false, false};
     size_t frames_cap = 0; // bytes per buffer
     int frames_cur = 0;
@@ -354,6 +368,29 @@ int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
     return PSDC_OK;
 }
 
+// compute-stream work enqueued from here on sees every upload enqueued so far
+int wait_uploads(psdc_handle *h)
+{
+    if (h->upload_pending) {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_upload, 0));
+        h->upload_pending = false;
+    }
+    return PSDC_OK;
+}
+// before an upload is enqueued: the copy stream waits for the latest round's post launch
+int order_upload(psdc_handle *h)
+{
+    if (h->post_marked)
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_post, 0));
+    return PSDC_OK;
+}
+int mark_upload(psdc_handle *h)
+{
+    HIPCHK(h, hipEventRecord(h->ev_upload, h->copy_stream));
+    h->upload_pending = true;
+    return PSDC_OK;
+}
+
 // make room for absolute indices [base, new_end) in the current buffer
 int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
 {
@@ -362,6 +399,9 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
         return PSDC_OK;
     {
         int rc = launch_deferred(h, {}); // a carried tail may still be on its way into this buffer
+        if (rc)
+            return rc;
+        rc = wait_uploads(h); // ... or an upload
         if (rc)
             return rc;
     }
@@ -474,6 +514,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // the new span in front of the in-place side
     const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * (uint64_t)g.hop : 0);
     *did_work = false;
+    {
+        int rc = wait_uploads(h);
+        if (rc)
+            return rc;
+    }
 
     // zero-copy spans: copy the seam (the part that completes segments begun in
     // the carried tail) behind the tail; the bulk is read in place.  One copy
@@ -525,6 +570,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         int rc = launch_deferred(h, seams); // with the last round's epilogue
         if (rc)
             return rc;
+        HIPCHK(h, hipEventRecord(h->ev_post, h->stream)); // see order_upload
+        h->post_marked = true;
     }
 
     // collect the work of this round from the totals as they stand now
@@ -979,9 +1026,17 @@ int submit_host(psdc_handle *h, Channel &c)
     if (rc)
         return rc;
     const int b = c.cur_stage;
+    rc = order_upload(h);
+    if (rc)
+        return rc;
     HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base), c.stage_host[b],
-                             sizeof(float) * c.fill, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipEventRecord(c.stage_ev[b], h->stream));
+                             sizeof(float) * c.fill, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(c.stage_ev[b], h->copy_stream));
+    {
+        int rc2 = mark_upload(h);
+        if (rc2)
+            return rc2;
+    }
     c.ev_pending[b] = true;
     s0.total += c.fill;
     s0.buf.end = s0.total;
@@ -1228,7 +1283,10 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
     };
     if ((e = hipSetDevice(device)) != hipSuccess)
         return dev_fail(e, "hipSetDevice");
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming)) != hipSuccess)
         return dev_fail(e, "hipStreamCreate");
     if ((e = hipMalloc(&h->d_win, sizeof(float) * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(win)");
@@ -1276,6 +1334,8 @@ void psdc_destroy(psdc_handle *h)
     if (!h)
         return;
     (void)hipSetDevice(h->device);
+    if (h->copy_stream)
+        (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     (void)collect_profile(h);
@@ -1299,6 +1359,8 @@ void psdc_destroy(psdc_handle *h)
             (void)hipHostFree(h->h_frames[i]);
         if (h->frames_ev[i])
             (void)hipEventDestroy(h->frames_ev[i]);
+        if (h->frames_dec_ev[i])
+            (void)hipEventDestroy(h->frames_dec_ev[i]);
     }
     if (h->d_win)
         (void)hipFree(h->d_win);
@@ -1308,6 +1370,12 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_tw0g);
     if (h->d_twag)
         (void)hipFree(h->d_twag);
+    if (h->ev_upload)
+        (void)hipEventDestroy(h->ev_upload);
+    if (h->ev_post)
+        (void)hipEventDestroy(h->ev_post);
+    if (h->copy_stream)
+        (void)hipStreamDestroy(h->copy_stream);
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1318,7 +1386,9 @@ int psdc_reset(psdc_handle *h)
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
     HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->upload_pending = false;
     h->pend_red.clear(); // the state they would update is discarded
     h->pend_tail.clear();
     h->idle = true;
@@ -1523,40 +1593,40 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
         return fail(h, PSDC_ERR_ARG, "null input");
     if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
         return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
-    // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25)
+    // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25) and keep the loss
+    // counters (Loss::update, src/loss.rs:11-26), piece by piece inside the upload loop below so
+    // that the scan of one piece runs while the piece before it is on the link
     size_t good = 0;
     int bad = PSDC_OK;
     const size_t payload = frame_size - 8;
     const int batches = (int)(payload / 64);
-    for (; good < n_frames; ++good) {
-        const uint8_t *f = frames + good * frame_size;
-        if (f[0] != 0x7b || f[1] != 0x05) {
-            bad = PSDC_ERR_FRAME_HEADER;
-            break;
+    auto scan = [&](size_t f0, size_t cnt) -> size_t { // frames accepted from f0 on; sets `bad` at the first bad one
+        for (size_t i = 0; i < cnt; ++i) {
+            const uint8_t *f = frames + (f0 + i) * frame_size;
+            if (f[0] != 0x7b || f[1] != 0x05) {
+                bad = PSDC_ERR_FRAME_HEADER;
+                return i;
+            }
+            if (f[2] != 1) { // unknown id, or Fls / ThermostatEem / Mpll: not AdcDac
+                bad = PSDC_ERR_FRAME_FORMAT;
+                return i;
+            }
+            if (payload % 64 != 0 || (int)f[3] != batches) {
+                bad = PSDC_ERR_FRAME_SIZE;
+                return i;
+            }
+            const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+            h->loss.received += f[3];
+            if (h->loss.have_seq)
+                h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
+            h->loss.next_seq = seq + f[3];                              // wrapping_add
+            h->loss.have_seq = 1;
         }
-        if (f[2] < 1 || f[2] > 4) {
-            bad = PSDC_ERR_FRAME_FORMAT;
-            break;
-        }
-        if (f[2] != 1) { // Fls / ThermostatEem / Mpll: not AdcDac
-            bad = PSDC_ERR_FRAME_FORMAT;
-            break;
-        }
-        if (payload % 64 != 0 || (int)f[3] != batches) {
-            bad = PSDC_ERR_FRAME_SIZE;
-            break;
-        }
-    }
-    for (size_t i = 0; i < good; ++i) { // Loss::update (src/loss.rs:11-26)
-        const uint8_t *f = frames + i * frame_size;
-        const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
-        h->loss.received += f[3];
-        if (h->loss.have_seq)
-            h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
-        h->loss.next_seq = seq + f[3];                              // wrapping_add
-        h->loss.have_seq = 1;
-    }
-    if (good > 0 && batches > 0) {
+        return cnt;
+    };
+    if (batches == 0) {
+        good = scan(0, n_frames); // header-only frames carry no samples
+    } else {
         // order behind anything pending on these channels
         bool pend = false;
         for (int ci = 0; ci < 4; ++ci)
@@ -1572,6 +1642,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
         const size_t piece_frames = std::max<size_t>(1, ((size_t)16 << 20) / frame_size);
         const size_t piece_bytes = piece_frames * frame_size;
         if (piece_bytes > h->frames_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->copy_stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             for (int i = 0; i < 2; ++i) {
                 if (h->d_frames[i])
@@ -1586,12 +1657,16 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                 if (!h->frames_ev[i])
                     HIPCHK(h, hipEventCreateWithFlags(&h->frames_ev[i], hipEventDisableTiming));
                 h->frames_ev_pending[i] = false;
+                h->frames_dec_pending[i] = false;
             }
             h->frames_cap = piece_bytes;
         }
         h->idle = false;
-        for (size_t f0 = 0; f0 < good; f0 += piece_frames) {
-            const size_t cnt = std::min(piece_frames, good - f0);
+        for (size_t f0 = 0; f0 < n_frames && bad == PSDC_OK; f0 += piece_frames) {
+            const size_t cnt = scan(f0, std::min(piece_frames, n_frames - f0));
+            good += cnt;
+            if (cnt == 0)
+                break;
             const size_t bytes = cnt * frame_size;
             const int b = h->frames_cur;
             if (h->frames_ev_pending[b]) { // the bounce buffer's last upload must have left it
@@ -1599,8 +1674,15 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                 h->frames_ev_pending[b] = false;
             }
             CopyPool::get().copy(h->h_frames[b], frames + f0 * frame_size, bytes);
-            HIPCHK(h, hipMemcpyAsync(h->d_frames[b], h->h_frames[b], bytes, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipEventRecord(h->frames_ev[b], h->stream));
+            if (h->frames_dec_pending[b]) { // the decode kernel of two pieces ago has read this device image
+                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->frames_dec_ev[b], 0));
+                h->frames_dec_pending[b] = false;
+            }
+            HIPCHK(h, hipMemcpyAsync(h->d_frames[b], h->h_frames[b], bytes, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(h, hipEventRecord(h->frames_ev[b], h->copy_stream));
+            rc = mark_upload(h);
+            if (rc)
+                return rc;
             h->frames_ev_pending[b] = true;
             h->frames_cur = b ^ 1;
             const size_t per_ch = cnt * (size_t)batches * 8;
@@ -1618,10 +1700,16 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                     return rc;
                 dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
             }
-            // (the device image d_frames[b] is next written two pieces later, behind this kernel
-            // in the stream)
+            rc = wait_uploads(h); // the decode kernel reads what the copy stream is bringing
+            if (rc)
+                return rc;
             HIPCHK(h, launch_adcdac(h->d_frames[b], frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3],
                                     h->stream));
+            // the device image d_frames[b] is written again two pieces later: that upload waits for this
+            if (!h->frames_dec_ev[b])
+                HIPCHK(h, hipEventCreateWithFlags(&h->frames_dec_ev[b], hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(h->frames_dec_ev[b], h->stream));
+            h->frames_dec_pending[b] = true;
             for (int ci = 0; ci < 4; ++ci) {
                 h->ch[ci].st[0].total += per_ch;
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
