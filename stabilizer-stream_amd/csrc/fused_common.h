@@ -76,8 +76,8 @@ __device__ __forceinline__ float dpp_shr1(float fill, float v)
 }
 __device__ __forceinline__ float dpp_ror1(float v)
 {
-    return __builtin_bit_cast(float,
-                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+    // every lane is written: no "old" operand (update_dpp with a 0 costs a v_mov_b32 to materialise it)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
 }
 
 // Sum over a row of 16 lanes with DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: plain

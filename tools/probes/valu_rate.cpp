@@ -12,6 +12,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float s
     for (int i = 0; i < ACC; ++i)
         a[i] = f2{seed + i + threadIdx.x, seed - i};
     f2 b = {seed * 0.5f, seed * 0.25f}, c = {seed * 0.125f, seed};
+    const float sc = __builtin_amdgcn_readfirstlane(seed * 0.75f);
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
@@ -27,8 +28,29 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float s
             } else if constexpr (MODE == 4) { // two scalar add
                 asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
                 asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i].y) : "v"(b.y));
-            } else { // packed fma with op_sel swizzle, as a complex multiply would use it
+            } else if constexpr (MODE == 5) { // packed fma with op_sel swizzle, as a complex multiply would use it
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(b), "v"(c));
+            } else if constexpr (MODE == 6) { // VOP2 accumulate form, three VGPR reads
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].y) : "v"(b.y), "v"(c.y));
+            } else if constexpr (MODE == 7) { // one factor in an SGPR
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "s"(sc), "v"(c.x));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i].y) : "s"(sc), "v"(c.y));
+            } else if constexpr (MODE == 8) { // accumulate form, one factor in an SGPR
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "s"(sc), "v"(c.x));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].y) : "s"(sc), "v"(c.y));
+            } else if constexpr (MODE == 9) { // x*x + acc: two distinct VGPRs
+                asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i].x) : "v"(b.x));
+                asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i].y) : "v"(b.y));
+            } else if constexpr (MODE == 10) {
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].y) : "v"(b.y));
+            } else if constexpr (MODE == 11) { // literal constant factor
+                asm volatile("v_fmamk_f32 %0, %0, 0x3f6c835e, %1" : "+v"(a[i].x) : "v"(c.x));
+                asm volatile("v_fmamk_f32 %0, %0, 0x3f6c835e, %1" : "+v"(a[i].y) : "v"(c.y));
+            } else { // sub then mul, the window's shape
+                asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].y) : "v"(c.y));
             }
         }
     }
@@ -64,12 +86,19 @@ template <int MODE> static void run(const char *name, int waves_per_simd)
 int main()
 {
     for (int w : {1, 2, 4}) {
-        run<0>("2 x v_fma_f32", w);
+        run<0>("2 x v_fma_f32 (v,v,v)", w);
+        run<6>("2 x v_fmac_f32 (v,v)", w);
+        run<7>("2 x v_fma_f32 (v,s,v)", w);
+        run<8>("2 x v_fmac_f32 (s,v)", w);
+        run<11>("2 x v_fmamk_f32 (v,lit,v)", w);
+        run<9>("2 x v_fmac_f32 (v,same v)", w);
+        run<10>("2 x v_mul_f32", w);
+        run<4>("2 x v_add_f32", w);
+        run<12>("v_sub_f32 + v_mul_f32", w);
         run<1>("v_pk_fma_f32", w);
         run<5>("v_pk_fma_f32 op_sel", w);
         run<2>("v_pk_mul_f32", w);
         run<3>("v_pk_add_f32", w);
-        run<4>("2 x v_add_f32", w);
     }
     return 0;
 }
