@@ -240,8 +240,9 @@ float psdc_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const fl
 int psdc_hbf_dec8(int device, const float *x, size_t len, float *y);
 
 /* Fill device memory with the bench/test stream: x_i = (u_i - 0.5) * sqrt(12),
- * u_i = (splitmix64(seed + first_index + i) >> 40) * 2^-24  (unit-variance
- * uniform noise, the reference's own test signal src/psd.rs:604-606). */
+ * u_i = (r_i >> 40) * 2^-24 with r_i output first_index + i of SplitMix64 seeded
+ * with mix64(seed + GAMMA), i.e. r_i = mix64(key + (first_index + i + 1) * GAMMA)
+ * (unit-variance uniform noise, the reference's own test signal src/psd.rs:604-606). */
 int psdc_fill_noise_device(int device, float *d_x, size_t len, uint64_t seed,
                            uint64_t first_index);
 

@@ -495,13 +495,19 @@ def fill_noise_device(ptr, length, seed, first_index=0, device=0):
 
 
 def noise_host(length, seed, first_index=0):
-    """Host twin of psdc_fill_noise_device: (u - 0.5) * sqrt(12), u from splitmix64 (src/psd.rs:604-606)."""
-    i = (np.arange(length, dtype=np.uint64) + np.uint64(first_index) + np.uint64(seed))
-    with np.errstate(over="ignore"):
-        x = i + np.uint64(0x9E3779B97F4A7C15)
+    """Host twin of psdc_fill_noise_device: (u - 0.5) * sqrt(12), u from SplitMix64 seeded with
+    mix64(seed + GAMMA), outputs first_index, first_index + 1, ... (src/psd.rs:604-606)."""
+    gamma = np.uint64(0x9E3779B97F4A7C15)
+
+    def mix64(x):
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        x = x ^ (x >> np.uint64(31))
+        return x ^ (x >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        key = mix64(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64) + gamma)[0]
+        i = np.arange(length, dtype=np.uint64) + np.uint64((first_index + 1) & 0xFFFFFFFFFFFFFFFF)
+        x = mix64(key + i * gamma)
     u = (x >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
     return ((u - np.float32(0.5)) * np.float32(3.4641016151377544)).astype(np.float32)
 

@@ -374,9 +374,11 @@ __global__ __launch_bounds__(RED_BINS *RED_SLICES) void post_kernel(const RedBat
         job.dst[i] = job.src[i];
 }
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+// SplitMix64: output i of the generator seeded with `key` is mix64(key + (i + 1) * GAMMA).  The stride matters:
+// hashing CONSECUTIVE integers (an earlier version) leaves structure at 2^24-sample scales that a ten-stage
+// cascade resolves as spectral lines in its deepest stages.
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
-    x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
@@ -386,8 +388,10 @@ __global__ __launch_bounds__(256) void fill_noise_kernel(float *x, size_t len, u
                                                          uint64_t first)
 {
     const float scale = 3.4641016151377544f; // sqrt(12), src/psd.rs:605
+    const uint64_t gamma = 0x9E3779B97F4A7C15ull;
+    const uint64_t key = mix64(seed + gamma); // seeds 1 apart (one per channel) give unrelated streams
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
-        const uint64_t r = splitmix64(seed + first + i);
+        const uint64_t r = mix64(key + (first + i + 1) * gamma);
         const float u = (float)(r >> 40) * 5.9604644775390625e-08f; // 2^-24
         x[i] = (u - 0.5f) * scale;
     }

@@ -3,7 +3,7 @@
 
 These are SELF-GENERATED regression vectors (the reference ships no recorded input/output
 files); they are not reference outputs.  Inputs are not stored: they are
-`noise_host(length, seed)` (splitmix64 -> unit-variance uniform noise, src/psd.rs:604-606)
+`noise_host(length, seed)` (SplitMix64 -> unit-variance uniform noise, src/psd.rs:604-606)
 plus a tone and an offset, regenerated bit-exactly by the tests.  Re-run after changing the
 half-band tap table (oracle/hbf_taps_oracle.h + stabilizer-stream_amd/csrc/hbf_taps.h).
 """

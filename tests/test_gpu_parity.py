@@ -572,6 +572,56 @@ def test_full_size_properties(pkg, gpu_required):
         h.close()
 
 
+def test_config5_ten_stages(pkg, gpu_required):
+    """BASELINE config 5: 1 channel, N = 16384, ten stages with a spectrum.  Stage 9 completes its first
+    segment after ~2.3e12 samples (N * 8^9 and the drains), which no buffer holds: a 2^28-sample device
+    buffer is refilled with the next stretch of the noise stream for every pass.  Size-independent checks:
+    the closed-form counters, the reference's white-noise bound in every included bin of every stage
+    (src/psd.rs:634-643), monotone frequencies, and stage 0's gain past the reference's u32 product
+    (src/psd.rs:282 wraps there)."""
+    import time
+    import torch
+    n, chunk = 16384, 1 << 28
+    passes = 1
+    while True:  # first pass count at which stage 9 has a segment
+        plan = pkg.plan_counts(n, passes * chunk)
+        if len(plan) > 9 and plan[9][1] >= 1:
+            break
+        passes += max(1, passes // 64)
+    d = [torch.empty(chunk, dtype=torch.float32, device="cuda") for _ in range(2)]
+    g = pkg.PsdCascadeBank(n)
+    t0 = time.perf_counter()
+    for i in range(passes):
+        buf = d[i & 1]
+        if i >= 2:
+            g.sync()  # a span is read in place until the device is done with it
+        pkg.fill_noise_device(buf.data_ptr(), chunk, seed=0x7654321, first_index=i * chunk)
+        g.process_device(0, buf.data_ptr(), chunk)
+    g.sync()
+    dt = time.perf_counter() - t0
+    total = passes * chunk
+    print(f"config 5: {total:.3e} samples in {dt:.1f} s = {total / dt / 1e9:.0f} GS/s with the refills, "
+          f"{g.num_stages()} stages")
+    assert g.num_stages() == len(plan) >= 10
+    for k, (recv, segs, pend) in enumerate(plan):
+        info = g.stage_info(0, k)
+        assert (info["count"], info["pending"]) == (segs, pend), k
+    p, br = g.psd()
+    assert sum(b.include for b in br) >= 10
+    f = pkg.Break.frequencies(br)
+    assert f[0] == 0.0 and f[-1] == 0.5 and np.all(np.diff(f) > 0)
+    for b in br:
+        if b.include:
+            seg = p[b.start:b.start + len(b.bins)].astype(np.float64)
+            if b.count >= 8:
+                assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(b.count)), b
+            else:  # a handful of segments: each bin is far from Gaussian (exponential at count 1); test the mean
+                assert abs(seg.mean() * 0.5 - 1.0) < 10.0 / np.sqrt(b.count * len(seg) / 2), b
+    assert plan[0][1] * (n // 2) > 0xFFFFFFFF  # the reference's u32 gain product has wrapped by now
+    assert g.stage_gain(0, 0) == pytest.approx(float(plan[0][1]) * (n // 2) * 0.375, rel=1e-6)
+    g.close()
+
+
 @pytest.mark.parametrize("n,seed", [(256, 1), (512, 2), (1024, 3), (1024, 4), (2048, 5), (64, 6), (1024, 7),
                                     (1024, 8), (512, 9), (4096, 10), (256, 11), (1024, 12)])
 def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
