@@ -572,6 +572,91 @@ def test_full_size_properties(pkg, gpu_required):
         h.close()
 
 
+def test_config3_full_size(pkg, gpu_required):
+    """BASELINE config 3 at its full size: 4-trace dual-iir frames (22 batches, 1416 B), N = 4096, 2^24 samples
+    per trace.  Size-independent checks: every frame counted once (src/loss.rs), closed-form counters, and
+    the spectra equal those of the same four traces decoded on the host (src/de/data.rs:28-35,64) and fed
+    as plain f32 streams."""
+    import torch
+    n, batches = 4096, 22
+    nframes = -(-(1 << 24) // (8 * batches))
+    per = nframes * 8 * batches
+    lsb = np.float32(4.096 * 2.5 / 32768.0)
+    words = np.stack([np.clip(np.round(pkg.noise_host(per, 0x7654321 + c).astype(np.float64) * 4096), -32768, 32767)
+                      .astype(np.int16) for c in range(4)])
+    wire = words.copy()
+    wire[2:] = (wire[2:].view(np.uint16) ^ np.uint16(0x8000)).view(np.int16)  # DAC words are offset-binary on the wire
+    data, fs = pkg.make_adcdac_frames(wire, batches, seq0=0xFFFFF000)  # the u32 sequence wraps on the way
+    assert fs == 1416 and len(data) == nframes * fs
+    g = pkg.PsdCascadeBank(n, 4)
+    assert g.process_adcdac_frames(data, fs) == nframes
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    plan = pkg.plan_counts(n, per)
+    assert sum(1 for _, segs, _ in plan if segs >= 1) >= 4
+    h = pkg.PsdCascadeBank(n, 4)
+    for c in range(4):
+        x = torch.from_numpy(words[c].astype(np.float32) * lsb).cuda()
+        h.process_device(c, x.data_ptr(), per)
+        h.sync()
+    for c in range(4):
+        assert g.num_stages(c) == len(plan)
+        for k, (recv, segs, pend) in enumerate(plan):
+            info = g.stage_info(c, k)
+            assert (info["count"], info["pending"]) == (segs, pend), (c, k)
+            if segs:
+                assert_psd_close(g.stage_spectrum(c, k), h.stage_spectrum(c, k), f"{pkg.ADCDAC_TRACES[c]} stage {k}")
+        p, br = g.psd(c)
+        for b in br:  # white noise of variance (4096 lsb)^2
+            if b.include and b.count >= 8:
+                seg = p[b.start:b.start + len(b.bins)] / (4096.0 * float(lsb)) ** 2
+                assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(b.count)), (c, b)
+    g.close()
+    h.close()
+
+
+def test_config4_one_gpu_share_full_size(pkg, gpu_required):
+    """BASELINE config 4, the share of one GPU: 8 of the 64 channels, N = 1024, 2^24 samples each, fed
+    round-robin in 2^22-sample spans.  Closed-form counters, the white-noise bound, each channel equal to
+    the same stream through a single-channel cascade, and the gathered read-out (shard.pack_readout ->
+    stitch_gathered, what rank 0 does after the RCCL gather) equal to psd() of the bank."""
+    import torch
+    from importlib import import_module
+    shard = import_module(pkg.__name__ + ".shard")
+    n, nch, total, span = 1024, 8, 1 << 24, 1 << 22
+    d = [torch.empty(total, dtype=torch.float32, device="cuda") for _ in range(nch)]
+    for c in range(nch):
+        pkg.fill_noise_device(d[c].data_ptr(), total, seed=0x7654321 + c)
+    g = pkg.PsdCascadeBank(n, nch)
+    for off in range(0, total, span):
+        for c in range(nch):
+            g.process_device(c, d[c].data_ptr() + 4 * off, span)
+    plan = pkg.plan_counts(n, total)
+    for c in range(nch):
+        assert g.num_stages(c) == len(plan)
+        for k, (recv, segs, pend) in enumerate(plan):
+            info = g.stage_info(c, k)
+            assert (info["count"], info["pending"]) == (segs, pend), (c, k)
+        p, br = g.psd(c)
+        for b in br:
+            if b.include:
+                seg = p[b.start:b.start + len(b.bins)]
+                assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(b.count)), (c, b)
+    assert not np.array_equal(g.stage_spectrum(0, 0), g.stage_spectrum(1, 0))  # the channels are different streams
+    for c in (0, nch - 1):
+        one = pkg.PsdCascadeBank(n, 1)
+        one.process_device(0, d[c].data_ptr(), total)
+        for k, (recv, segs, pend) in enumerate(plan):
+            if segs:
+                assert_psd_close(g.stage_spectrum(c, k), one.stage_spectrum(0, k), f"channel {c} stage {k}")
+        one.close()
+    spec, meta = shard.pack_readout(g, nch, n)
+    merged = shard.stitch_gathered(pkg, n, [spec], [meta], [nch])
+    for c in range(nch):
+        p, br = g.psd(c)
+        assert np.array_equal(merged[c][0], p) and len(merged[c][1]) == len(br)
+    g.close()
+
+
 def test_config5_ten_stages(pkg, gpu_required):
     """BASELINE config 5: 1 channel, N = 16384, ten stages with a spectrum.  Stage 9 completes its first
     segment after ~2.3e12 samples (N * 8^9 and the drains), which no buffer holds: a 2^28-sample device
