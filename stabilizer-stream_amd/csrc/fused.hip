@@ -219,6 +219,19 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
 #pragma unroll
     for (int r = 0; r < HR; ++r)
         hreg[r] = (HREG && tl + TEAM * r < G::HIST) ? hs[tl + TEAM * r] : 0.0f;
+    // Mean (src/psd.rs:103-109): the offset of a segment is pivot + m, the pivot a value close to the mean
+    // (x - pivot is exact when a DC level dwarfs the noise, small otherwise) and m the mean of the residuals
+    // (tiny, so its rounding does not matter; a single rounded offset would be a coherent error of half an
+    // ulp of the mean over the segment, i.e. in bins 0 and 1).  The pivot is carried from pair to pair --
+    // the mean found for the segment before -- so every sample is centred once and every half-segment
+    // summed once: piv, and s0c = the sum of (lo - piv) over the team.
+    float piv = 0.0f, s0c = 0.0f;
+    if constexpr (DETREND == 3) {
+        auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
+        piv = team_sum<TEAM>((r4(ga[0]) + r4(ga[1])) + (r4(gb[0]) + r4(gb[1]))) * (1.0f / (float)N);
+        auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
+        s0c = team_sum<TEAM>(s4(ga[0], piv) + s4(ga[1], piv));
+    }
     PSDK_STAMP(10); // first loads issued + warm-up
     // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
     // nl = lower half of chunk p + 1.  Once lo/up have been windowed into the FFT registers
@@ -341,23 +354,27 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
                 sa = span_slope(oa, team_bcast<TEAM>(up[1].w, l0, TEAM - 1), N);
                 ob = team_bcast<TEAM>(up[0].x, l0, 0);
                 sb = span_slope(ob, team_bcast<TEAM>(nl[1].w, l0, TEAM - 1), N);
-            } else if constexpr (DETREND == 3) { // Mean (src/psd.rs:103-109) in two steps
-                // o = the f32 mean of the raw samples (a pivot close to the true mean: with a DC level
-                // far above the noise x - o is exact, without one it is a small number), m = the mean of
-                // the residuals x - o (tiny, so ITS rounding does not matter).  A single f32 offset
-                // would be rounded at ulp(|mean|), a pivot on a sample at ulp(|sample|) -- either is a
-                // coherent offset over the segment, i.e. an error in bins 0 and 1.
+            } else if constexpr (DETREND == 3) { // Mean, pivot carried (see above)
+                auto sub4 = [](float4 &x, float pv) {
+                    x.x -= pv;
+                    x.y -= pv;
+                    x.z -= pv;
+                    x.w -= pv;
+                };
+                sub4(lo[0], piv); // lo and up are dead after the window: centred in place
+                sub4(lo[1], piv);
+                sub4(up[0], piv);
+                sub4(up[1], piv);
                 auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
-                const float rl = r4(lo[0]) + r4(lo[1]), ru = r4(up[0]) + r4(up[1]), rn = r4(nl[0]) + r4(nl[1]);
-                oa = team_sum<TEAM>(rl + ru) * (1.0f / (float)N);
-                ob = team_sum<TEAM>(ru + rn) * (1.0f / (float)N);
                 auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
-                const float sl = s4(lo[0], oa) + s4(lo[1], oa);
-                const float sua = s4(up[0], oa) + s4(up[1], oa);
-                const float sub = s4(up[0], ob) + s4(up[1], ob);
-                const float sn = s4(nl[0], ob) + s4(nl[1], ob);
-                ma = team_sum<TEAM>(sl + sua) * (1.0f / (float)N);
-                mb = team_sum<TEAM>(sub + sn) * (1.0f / (float)N);
+                const float s1 = team_sum<TEAM>(r4(up[0]) + r4(up[1]));
+                const float s2 = team_sum<TEAM>(s4(nl[0], piv) + s4(nl[1], piv)); // nl stays raw: the next decimator reads it
+                ob = piv;
+                ma = (s0c + s1) * (1.0f / (float)N);
+                mb = (s1 + s2) * (1.0f / (float)N);
+                const float pnext = piv + mb; // the mean of segment b
+                s0c = fmaf(-(float)(N / 2), pnext - piv, s2); // nl becomes lo: its sum about the new pivot
+                piv = pnext;
             }
             if constexpr (EWMA) {
                 if (job.ewma) {
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
                     dp.eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
                 }
             }
-            window_pair<N, DETREND, EWMA>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
+            window_pair<N, DETREND, EWMA, true>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
                                           s_win[2 * TEAM + tl], s_win[3 * TEAM + tl], dp);
         }
         { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT.  Issued

@@ -170,7 +170,9 @@ struct DetrendParams {
     slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
     float ea = 1.0f, eb = 1.0f; // EWMA amplitudes
 };
-template <int N, int DETREND, bool EWMA>
+// CENTRED (Mean only): lo and up arrive with the pivot d.ob already subtracted (they are dead afterwards and
+// were rewritten in place), nl is raw.
+template <int N, int DETREND, bool EWMA, bool CENTRED = false>
 __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &lo0, const float4 &lo1, const float4 &up0,
                                             const float4 &up1, const float4 &nl0, const float4 &nl1, const float4 &w0,
                                             const float4 &w1, const float4 &w2, const float4 &w3, const DetrendParams &d)
@@ -184,6 +186,9 @@ __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &l
             const float n = nf + (float)nofs;
             xa = fmaf(-n, d.sa.lo, fmaf(-n, d.sa.hi, xa - d.oa));
             xb = fmaf(-n, d.sb.lo, fmaf(-n, d.sb.hi, xb - d.ob));
+        } else if constexpr (DETREND == 3 && CENTRED) {
+            xa -= d.ma;
+            xb = slot < 8 ? xb - d.mb : (xb - d.ob) - d.mb;
         } else if constexpr (DETREND == 3) {
             xa = (xa - d.oa) - d.ma;
             xb = (xb - d.ob) - d.mb;

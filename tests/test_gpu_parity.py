@@ -78,6 +78,30 @@ def test_detrend_parity(pkg, ora, gpu_required, n, detrend):
     g.close()
 
 
+@pytest.mark.parametrize("n", [256, 1024, 4096])
+def test_mean_detrend_level_steps(pkg, ora, gpu_required, n):
+    """Detrend::Mean (src/psd.rs:103-109) on a stream whose level jumps by orders of magnitude: the kernels
+    carry the pivot of the mean from segment to segment, so a jump is the case where the carried pivot is
+    far from the segment it meets.  Device-resident feed in two uneven spans (long runs of pairs)."""
+    import torch
+    rng = np.random.default_rng(n)
+    total = 600 * n + 8 * 77
+    x = pkg.noise_host(total, seed=900 + n).astype(np.float64)
+    edges = np.sort(rng.integers(0, total, size=9))
+    levels = [0.0, 1000.0, -500.0, 3.0e4, 3.0e4 + 7.0, 0.25, -2.0e3, 1.0e5, 0.0, 12.0]
+    for lv, a, b in zip(levels, np.r_[0, edges], np.r_[edges, total]):
+        x[a:b] += lv
+    x = x.astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    g = pkg.PsdCascadeBank(n)
+    g.set_detrend(pkg.Detrend.MEAN)
+    cut = (total // 3) & ~7
+    g.process_device(0, d.data_ptr(), cut)
+    g.process_device(0, d.data_ptr() + 4 * cut, total - cut)
+    check_against_oracle(pkg, ora, g, [x], n, detrend="mean", what=f"N={n} mean, level steps")
+    g.close()
+
+
 def test_reference_statistical_test(pkg, gpu_required):
     """src/psd.rs:599-644 verbatim (Psd<512> and PsdCascade<512> on unit white noise)."""
     rng = np.random.default_rng()  # unseeded like the reference's rand::random
