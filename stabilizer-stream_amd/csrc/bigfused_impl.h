@@ -125,6 +125,38 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         __syncthreads();
     }
 
+    // Mean (src/psd.rs:103-109) with a carried pivot, as in fused.hip: the offset of a segment is piv + m,
+    // piv the mean found for the segment before (for the first segment of the run: its own f32 mean), m
+    // the mean of the residuals.  s0c = sum of (lo - piv) over the workgroup.
+    float piv = 0.0f, s0c = 0.0f;
+    if constexpr (DETREND == 3) {
+        auto block_sum = [&](float v) { // sum over the workgroup, the same value in every thread
+            v = wave_sum64(v);
+            __syncthreads(); // s_red free
+            if ((tp & 63) == 0)
+                s_red[4 + (tp >> 6)] = v;
+            __syncthreads();
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < G::WAVES; ++w)
+                t += s_red[4 + w];
+            return t;
+        };
+        auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
+        auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
+        float r = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+            r += (r4(ga[v][0]) + r4(ga[v][1])) + (r4(gb[v][0]) + r4(gb[v][1]));
+        piv = block_sum(r) * (1.0f / (float)N);
+        r = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+            r += s4(ga[v][0], piv) + s4(ga[v][1], piv);
+        s0c = block_sum(r);
+        __syncthreads(); // s_red is written again in the first pair
+    }
+
     // With several lanes per thread the scheduler must not interleave their sections (it would keep
     // every lane's butterflies and twiddles live at once): a scheduling barrier between lanes.
     auto lane_fence = [] {
@@ -220,6 +252,32 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 s_red[3] = nl[VT - 1][1].w;
             }
         }
+        if constexpr (DETREND == 3) { // centre lo and up in place (dead after the window); partial sums of up, nl
+            auto sub4 = [](float4 &x, float pv) {
+                x.x -= pv;
+                x.y -= pv;
+                x.z -= pv;
+                x.w -= pv;
+            };
+            auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
+            auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                sub4(lo[v][0], piv);
+                sub4(lo[v][1], piv);
+                sub4(up[v][0], piv);
+                sub4(up[v][1], piv);
+                t1 += r4(up[v][0]) + r4(up[v][1]);
+                t2 += s4(nl[v][0], piv) + s4(nl[v][1], piv); // nl stays raw: it is the next pair's lo
+            }
+            t1 = wave_sum64(t1);
+            t2 = wave_sum64(t2);
+            if ((tp & 63) == 0) {
+                s_red[4 + 2 * (tp >> 6)] = t1;
+                s_red[5 + 2 * (tp >> 6)] = t2;
+            }
+        }
         __syncthreads(); // the frame is reused by the FFT; s_red published
         if constexpr (DETREND == 1) {
             oa = s_red[0];
@@ -230,47 +288,19 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sa = span_slope(oa, s_red[2], N);
             sb = span_slope(ob, s_red[3], N);
         }
-        if constexpr (DETREND == 3) { // Mean in two steps: o = f32 mean of the samples, m = mean of x - o
-            // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
-            auto block_sum2 = [&](float &pa, float &pb) { // both sums over the workgroup, same value in every thread
-                pa = wave_sum64(pa);
-                pb = wave_sum64(pb);
-                if ((tp & 63) == 0) {
-                    s_red[4 + 2 * (tp >> 6)] = pa;
-                    s_red[5 + 2 * (tp >> 6)] = pb;
-                }
-                __syncthreads();
-                pa = 0.0f;
-                pb = 0.0f;
+        if constexpr (DETREND == 3) { // (s_red is next written a pair later, several barriers on)
+            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-                for (int w = 0; w < G::WAVES; ++w) {
-                    pa += s_red[4 + 2 * w];
-                    pb += s_red[5 + 2 * w];
-                }
-                __syncthreads(); // s_red is reused by the second sum
-            };
-            auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
-            float ra = 0.0f, rb = 0.0f;
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const float rl = r4(lo[v][0]) + r4(lo[v][1]), ru = r4(up[v][0]) + r4(up[v][1]);
-                const float rn = r4(nl[v][0]) + r4(nl[v][1]);
-                ra += rl + ru;
-                rb += ru + rn;
+            for (int w = 0; w < G::WAVES; ++w) {
+                s1 += s_red[4 + 2 * w];
+                s2 += s_red[5 + 2 * w];
             }
-            block_sum2(ra, rb);
-            oa = ra * (1.0f / (float)N);
-            ob = rb * (1.0f / (float)N);
-            auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
-            float pa = 0.0f, pb = 0.0f;
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                pa += s4(lo[v][0], oa) + s4(lo[v][1], oa) + s4(up[v][0], oa) + s4(up[v][1], oa);
-                pb += s4(up[v][0], ob) + s4(up[v][1], ob) + s4(nl[v][0], ob) + s4(nl[v][1], ob);
-            }
-            block_sum2(pa, pb);
-            ma = pa * (1.0f / (float)N);
-            mb = pb * (1.0f / (float)N);
+            ob = piv;
+            ma = (s0c + s1) * (1.0f / (float)N);
+            mb = (s1 + s2) * (1.0f / (float)N);
+            const float pnext = piv + mb;
+            s0c = fmaf(-(float)(N / 2), pnext - piv, s2);
+            piv = pnext;
         }
 
         // ---- FFT of the pair ---------------------------------------------------------------
@@ -285,7 +315,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
             const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
-            window_pair<N, DETREND, EWMA>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wp[0],
+            window_pair<N, DETREND, EWMA, true>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wp[0],
                                           wp[TEAM], wp[2 * TEAM], wp[3 * TEAM], dp);
             // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
             // go one after the other between two barriers)
