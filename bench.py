@@ -118,9 +118,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PSD_BENCH_FORCE_DIST"):  # (forced: a 1-rank group, to run the RCCL calls on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -158,8 +161,13 @@ def main():
     bank.configure(profile=True)  # HIP events around every dominant-kernel launch, on the library's stream
     for _ in range(args.warmup):
         step()
-    if args.warmup:
-        shard.pack_readout(bank, C, n, torch)  # first-use costs of the read-out path belong to the warm-up
+    if args.warmup or dist is not None:
+        # first-use costs of the read-out path belong to the warm-up: pinned read-out buffers, and for N > 1
+        # the gather's point-to-point connections, which RCCL sets up on the first call that uses them
+        wspec, wmeta = shard.pack_readout(bank, C, n, torch)
+        if dist is not None:
+            shard.gather_readout(dist, wspec, wmeta,
+                                 device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     barrier()
     prof0 = bank.profile_read()  # launches of the warm-up (kept: rocprofv3 --stats sees them too)
     t0 = time.perf_counter()

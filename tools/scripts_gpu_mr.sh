@@ -7,3 +7,6 @@ echo "rc=$rc"; grep '^{' gpurun_out/bench_mr.log | cut -c1-600 || tail -20 gpuru
 [ $rc -eq 0 ] || tail -20 gpurun_out/bench_mr.log
 timeout -k 10 300 python bench.py --steps 100 --warmup 5 --cpu-seconds 6 > gpurun_out/bench_default.log 2>&1
 echo "rc=$?"; grep '^{' gpurun_out/bench_default.log
+# the RCCL calls of the N > 1 path (init with device_id, barrier, device-tensor gather, all_reduce) in a 1-rank group
+PSD_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_rccl1.log 2>&1
+echo "rccl 1-rank rc=$?"; grep '^{' gpurun_out/bench_rccl1.log | cut -c1-300 || tail -20 gpurun_out/bench_rccl1.log
