@@ -44,31 +44,35 @@ def pack_readout(bank, n_local, n, torch=None, pad_to=None):
 
 def gather_readout(dist, spec, meta, device=None, dst=0):
     """One gather of (spec, meta) to rank `dst`.  All ranks must hold equally shaped arrays
-    (numpy or CPU tensors).  Returns lists of numpy arrays on dst, (None, None) elsewhere."""
+    (numpy or CPU tensors).  Returns lists of numpy arrays on dst, (None, None) elsewhere.
+    The payload is packed on the host (one H2D copy, one collective, one D2H copy on `dst`)."""
     import torch
-    spec = torch.from_numpy(np.ascontiguousarray(np.asarray(spec), dtype=np.float32))
-    meta = torch.from_numpy(np.ascontiguousarray(np.asarray(meta), dtype=np.int64))
+    spec = np.ascontiguousarray(np.asarray(spec), dtype=np.float32)
+    meta = np.ascontiguousarray(np.asarray(meta), dtype=np.int64)
+    rows = spec.shape[0]
+    nb = spec.shape[1] * spec.shape[2]
+    nm = meta.shape[1] * meta.shape[2]
+    # a single f32 payload: meta is carried as two exact halves (values < 2^48 split into 24-bit words)
+    pay = np.empty((rows, nb + 2 * nm), dtype=np.float32)
+    pay[:, :nb] = spec.reshape(rows, nb)
+    m = meta.reshape(rows, nm)
+    pay[:, nb:nb + nm] = (m & 0xFFFFFF).astype(np.float32)
+    pay[:, nb + nm:] = (m >> 24).astype(np.float32)
+    payload = torch.from_numpy(pay)
     if device is not None:
-        spec, meta = spec.to(device), meta.to(device)
+        payload = payload.to(device)
     rank, world = dist.get_rank(), dist.get_world_size()
-    # a single payload: meta is carried as two exact f32 halves (values < 2^48 split into 24-bit words)
-    lo = (meta & 0xFFFFFF).to(torch.float32)
-    hi = (meta >> 24).to(torch.float32)
-    payload = torch.cat([spec.reshape(spec.shape[0], -1), lo.reshape(lo.shape[0], -1),
-                         hi.reshape(hi.shape[0], -1)], dim=1).contiguous()
     out = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
     dist.gather(payload, out, dst=dst)
     if rank != dst:
         return None, None
-    nb = spec.shape[1] * spec.shape[2]
-    nm = meta.shape[1] * meta.shape[2]
+    got = torch.stack(out).cpu().numpy() if device is not None else [p.numpy() for p in out]
     specs, metas = [], []
-    for p in out:
-        p = p.cpu().numpy()
-        specs.append(p[:, :nb].reshape(tuple(spec.shape)))
+    for p in got:
+        specs.append(p[:, :nb].reshape(spec.shape))
         lo_ = p[:, nb:nb + nm].astype(np.int64)
         hi_ = p[:, nb + nm:nb + 2 * nm].astype(np.int64)
-        metas.append(((hi_ << 24) | lo_).reshape(tuple(meta.shape)))
+        metas.append(((hi_ << 24) | lo_).reshape(meta.shape))
     return specs, metas
 
 
