@@ -127,7 +127,7 @@ struct psdc_handle {
     size_t frames_cap = 0; // bytes per buffer
     int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
-    uint32_t coalesce = 4; // zero-copy spans per channel held back while the device is busy (1 = none)
+    uint32_t coalesce = 8; // zero-copy spans per channel held back while the device is busy (1 = none)
     bool coalesce_always = false; // hold them back even when the device is idle (tests)
     bool profile = false;
     std::vector<ProfEvents> prof_pending;

@@ -749,7 +749,7 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     torch.cuda.synchronize()
     g = pkg.PsdCascadeBank(n, nch)
     g.configure(quantum=int(rng.integers(2, 20)) * n,
-                coalesce=int(rng.choice([1, 4, -2, -4, -8])))  # negative: in-place spans held back unconditionally
+                coalesce=int(rng.choice([1, 4, 8, -2, -4, -8])))  # negative: in-place spans held back unconditionally
     refs = [ora.PsdCascade(n, "f64") for _ in range(nch)]
     pos = [0] * nch
     detrends = ["none", "midpoint", "span", "mean"]
