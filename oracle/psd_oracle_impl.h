@@ -341,7 +341,10 @@ static long SFX(psd_process)(SFX(ora_psd) * s, const REAL *x, size_t xlen, REAL 
         /* EWMA :218-225 */
         REAL g;
         if (s->count > s->avg) {
-            g = (REAL)s->avg / (REAL)s->count;
+            /* `avg as f32 / count as f32` (:220): the factor is DEFINED in f32 -- its rounding (3e-8) is part of
+             * the algorithm, and 1/(1 - g) turns it into 3e-5 of a long exponential average -- so the f64
+             * instantiation takes the f32 quotient too and only widens it */
+            g = (REAL)((float)s->avg / (float)s->count);
             s->count = s->avg;
         } else {
             g = (REAL)1.0;

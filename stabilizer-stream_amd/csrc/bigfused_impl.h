@@ -157,6 +157,12 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         __syncthreads(); // s_red is written again in the first pair
     }
 
+    EwmaAmp eamp;
+    if constexpr (EWMA) {
+        if (job.ewma)
+            eamp.init(job, job.step0 + 2 * p0);
+    }
+
     // With several lanes per thread the scheduler must not interleave their sections (it would keep
     // every lane's butterflies and twiddles live at once): a scheduling barrier between lanes.
     auto lane_fence = [] {
@@ -307,8 +313,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         cf vv[VT][16];
         if constexpr (EWMA) {
             if (job.ewma) {
-                dp.ea = fused_ewma_amp(job, job.step0 + 2 * p);
-                dp.eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
+                dp.eb = eamp.next(job);
             }
         }
 #pragma unroll

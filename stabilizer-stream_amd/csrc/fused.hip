@@ -82,10 +82,13 @@ __device__ __forceinline__ float team_sum(float v)
 
 // DETREND: 0 None, 1 Midpoint, 2 Span, 3 Mean (src/psd.rs:75-113).  EWMA: per-segment
 // amplitude sqrt(W) so that the two-for-one identity still yields the weighted sum.
-// The Span / Mean / EWMA variants need a few more registers than the 128 that four
-// wavefronts per SIMD allow; they are built for two per SIMD rather than spilling.
+// The Span / Mean / EWMA variants need a few more registers than the 128 that four wavefronts
+// per SIMD allow: they spill a few dwords outside the loop rather than halve the occupancy.
+#ifndef PSDK_EWMA_WPS
+#define PSDK_EWMA_WPS FUSED_WAVES_PER_SIMD // the EWMA variants too (6 dwords spilled outside the loop; 2 waves/SIMD read 10 % lower)
+#endif
 template <int N, int DETREND, bool EWMA>
-__global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) void fused_kernel(
+__global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVES_PER_SIMD) void fused_kernel(
     const FusedBatch batch, const float *__restrict__ win)
 {
     using G = FusedGeo<N>;
@@ -231,6 +234,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
         piv = team_sum<TEAM>((r4(ga[0]) + r4(ga[1])) + (r4(gb[0]) + r4(gb[1]))) * (1.0f / (float)N);
         auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
         s0c = team_sum<TEAM>(s4(ga[0], piv) + s4(ga[1], piv));
+    }
+    EwmaAmp eamp;
+    if constexpr (EWMA) {
+        if (job.ewma)
+            eamp.init(job, job.step0 + 2 * p0);
     }
     PSDK_STAMP(10); // first loads issued + warm-up
     // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
@@ -378,8 +386,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? 2 : FUSED_WAVES_PER_SIMD) 
             }
             if constexpr (EWMA) {
                 if (job.ewma) {
-                    dp.ea = fused_ewma_amp(job, job.step0 + 2 * p);
-                    dp.eb = fused_ewma_amp(job, job.step0 + 2 * p + 1);
+                    dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
+                    dp.eb = eamp.next(job);
                 }
             }
             window_pair<N, DETREND, EWMA, true>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],

@@ -161,6 +161,35 @@ __device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
     return (float)exp2(0.5 * (double)na * job.log2_gamma);
 }
 
+// The same amplitudes for consecutive steps of a run: one exp2 at the start, then a double multiplication per
+// step (the exponent drops by one per step between i_s - 1 and nb) instead of a double exp2 per segment.
+struct EwmaAmp {
+    double a = 1.0, rho = 1.0;
+    int step = 0;
+    bool zero = false; // gamma == 0 (avg == 0): weights are 0 or 1
+    __device__ __forceinline__ void init(const FusedJob &job, int s)
+    {
+        step = s;
+        zero = !(job.log2_gamma > -1.0e300);
+        rho = zero ? 0.0 : exp2(-0.5 * job.log2_gamma);
+        const int m = s > job.is_m1 ? s : job.is_m1;
+        const int na = job.nb - m;
+        a = na <= 0 ? 1.0 : (zero ? 0.0 : exp2(0.5 * (double)na * job.log2_gamma));
+    }
+    __device__ __forceinline__ float next(const FusedJob &job)
+    {
+        const float r = (float)a;
+        if (step >= job.is_m1 && step < job.nb) {
+            if (step + 1 >= job.nb)
+                a = 1.0;
+            else if (!zero)
+                a *= rho;
+        }
+        ++step;
+        return r;
+    }
+};
+
 // Detrend + window + EWMA amplitude of one segment pair into the 16 FFT inputs of a lane
 // (src/psd.rs:75-113, :211): lane tl holds samples 4 tl + c + (N/4) m of segment a in (lo0, lo1, up0,
 // up1)[m].c and of segment b in (up0, up1, nl0, nl1)[m].c; slot 4m + c gets

@@ -154,6 +154,25 @@ def test_chunking_invariance(pkg, ora, gpu_required):
     many.close()
 
 
+@pytest.mark.parametrize("n", [256, 1024, 4096, 16384])
+@pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (1000, 100000), (0, 7), (1, 1), (40, 3000)])
+def test_ewma_long_runs_device(pkg, ora, gpu_required, limit, count, n):
+    """Finite averaging over device-resident spans: long runs of segment pairs per workgroup, where the kernels
+    step the per-segment amplitude sqrt(gamma^k) by a running product from one exp2 per run."""
+    import torch
+    total = (1 << 22) + 8 * 311
+    x = make_signal(pkg, total, seed=23 + n, tone=0.2)
+    d = torch.from_numpy(x).cuda()
+    avg = pkg.AvgOpts(limit, count)
+    g = pkg.PsdCascadeBank(n)
+    g.set_avg(avg)
+    cut = (total // 5) & ~7
+    g.process_device(0, d.data_ptr(), cut)
+    g.process_device(0, d.data_ptr() + 4 * cut, total - cut)
+    check_against_oracle(pkg, ora, g, [x], n, avg=avg, what=f"ewma {limit},{count} N={n}, device spans")
+    g.close()
+
+
 @pytest.mark.parametrize("n", [64, 256, 512, 1024, 4096])
 @pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (0xFFFFFFFF, 40), (5, 1000), (0, 7), (1, 1)])
 def test_ewma_parity(pkg, ora, gpu_required, limit, count, n):
