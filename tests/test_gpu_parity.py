@@ -154,6 +154,31 @@ def test_chunking_invariance(pkg, ora, gpu_required):
     many.close()
 
 
+@pytest.mark.parametrize("n", [512, 1024, 4096, 8192])
+@pytest.mark.parametrize("detrend", ["none", "midpoint", "span", "mean"])
+@pytest.mark.parametrize("avg", [None, (40, 3000)])
+def test_long_device_runs_matrix(pkg, ora, gpu_required, n, detrend, avg):
+    """Every kernel variant (detrend x plain sum / finite averaging) on device-resident spans of millions of
+    samples -- long runs of segment pairs per workgroup, several stages live -- against the f64 oracle."""
+    import torch
+    total = (1 << 22) + 8 * 129
+    # (an offset only where the detrend is not anchored on one sample: by stage 4 it is x4096 against x64 for the
+    # noise, and Midpoint / Span then sit at the f32 resolution of the stream in bins 0-1, in the reference too --
+    # that regime has its own tests, test_large_dc_no_worse_than_f32_reference and the anchored stress tolerance)
+    x = make_signal(pkg, total, seed=301 + n, tone=0.3, dc=0.5 if detrend in ("none", "mean") else 0.0)
+    d = torch.from_numpy(x).cuda()
+    g = pkg.PsdCascadeBank(n)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    a = pkg.AvgOpts(*avg) if avg else None
+    if a:
+        g.set_avg(a)
+    cut = (total // 3) & ~7
+    g.process_device(0, d.data_ptr(), cut)
+    g.process_device(0, d.data_ptr() + 4 * cut, total - cut)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, avg=a, what=f"N={n} {detrend} avg={avg}, device spans")
+    g.close()
+
+
 @pytest.mark.parametrize("n", [256, 1024, 4096, 16384])
 @pytest.mark.parametrize("limit,count", [(3, 0xFFFFFFFF), (1000, 100000), (0, 7), (1, 1), (40, 3000)])
 def test_ewma_long_runs_device(pkg, ora, gpu_required, limit, count, n):
