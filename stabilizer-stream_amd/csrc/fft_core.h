@@ -54,14 +54,15 @@ PSDK_HD slope2 span_slope(float first, float last, int n)
     const float bp = dh - last;
     const float dl = (last - (dh - bp)) + (-first - bp);
     const float nm1 = (float)(n - 1);
-    slope2 s;
-    s.hi = dh / nm1;
+    const float r = 1.0f / nm1; // (n is a constant at the call sites.)  hi need not be the correctly rounded
+    slope2 s;                   // quotient: whatever it misses is in the remainder, and so in lo
+    s.hi = dh * r;
 #if defined(__HIP_DEVICE_COMPILE__)
     const float rem = __fmaf_rn(-s.hi, nm1, dh) + dl;
 #else
     const float rem = (float)((double)dh - (double)s.hi * (double)nm1) + dl;
 #endif
-    s.lo = rem / nm1;
+    s.lo = rem * r;
     return s;
 }
 
