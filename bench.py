@@ -177,7 +177,8 @@ def main():
         scratch.close()
     else:
         prof_scratch = None
-    bank.configure(profile=True)  # HIP events around every dominant-kernel launch, on the library's stream
+    if not os.environ.get("PSD_BENCH_NO_PROFILE"):  # (debug: what the event stamping itself costs)
+        bank.configure(profile=True)  # HIP events around every dominant-kernel launch, on the library's stream
     for _ in range(args.warmup):
         step()
     if args.warmup or dist is not None:
