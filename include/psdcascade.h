@@ -61,7 +61,7 @@ extern "C" {
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
 #define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that may share one round while the device is
-                             * still busy with earlier ones (1..8, default 8; 1 = every span its own round;
+                             * still busy with earlier ones (1..16, default 8; 1 = every span its own round;
                              * -k: hold k spans back even on an idle device -- for tests) */
 #define PSDC_OPT_PROFILE 2 /* 1: time the dominant kernel with HIP events (psdc_profile_read) */
 

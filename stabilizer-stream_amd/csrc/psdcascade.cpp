@@ -455,7 +455,7 @@ int ensure_partial(psdc_handle *h, size_t floats)
     return PSDC_OK;
 }
 
-constexpr int MAX_COALESCE = 8; // zero-copy spans of one channel in one round
+constexpr int MAX_COALESCE = 16; // zero-copy spans of one channel in one round
 
 struct Span { // one contiguous source of a (channel, stage) batch
     const float *src;

@@ -574,7 +574,7 @@ def test_past_the_u32_gain_overflow(pkg, gpu_required):
     g.close()
 
 
-@pytest.mark.parametrize("n,coalesce", [(1024, -2), (1024, -4), (1024, -8), (512, -3), (4096, -4), (1024, 4)])
+@pytest.mark.parametrize("n,coalesce", [(1024, -2), (1024, -4), (1024, -8), (512, -3), (4096, -4), (1024, 4), (1024, -16), (256, -13), (8192, -16)])
 def test_coalesced_spans(pkg, ora, gpu_required, n, coalesce):
     """PSDC_OPT_COALESCE: several in-place device spans of one channel go out as ONE round (each
     with its own seam region between it and the span before).  Negative values hold spans back even
@@ -599,6 +599,28 @@ def test_coalesced_spans(pkg, ora, gpu_required, n, coalesce):
             assert g.stage_info(0, 0) == ref.stage_info(0)
     g.sync()
     check_against_oracle(pkg, ora, g, chunks, n, what=f"coalesce {coalesce}")
+    g.close()
+
+
+@pytest.mark.parametrize("n,coalesce", [(1024, -16), (256, -11), (4096, -16), (1024, 16), (16384, -9)])
+def test_coalesced_spans_deep(pkg, ora, gpu_required, n, coalesce):
+    """Up to 16 held spans in one round: 26 spans of mixed lengths (some shorter than a segment, some not
+    a multiple of the hop), no read-out in between."""
+    import torch
+    rng = np.random.default_rng(abs(coalesce) * 1000 + n)
+    lens = [int(rng.choice([rng.integers(1, 3) * 8, rng.integers(1, 40) * n + 4 * rng.integers(0, 64),
+                            rng.integers(40, 200) * n, 4 * (n + 288)])) for _ in range(26)]
+    x = make_signal(pkg, sum(lens), seed=1900 + n, tone=0.25)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 1)
+    g.configure(coalesce=coalesce)
+    chunks, a = [], 0
+    for m in lens:
+        g.process_device(0, xd.data_ptr() + 4 * a, m)
+        chunks.append(x[a:a + m])
+        a += m
+    check_against_oracle(pkg, ora, g, chunks, n, what=f"coalesce {coalesce}, 26 spans")
     g.close()
 
 
@@ -793,7 +815,7 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     torch.cuda.synchronize()
     g = pkg.PsdCascadeBank(n, nch)
     g.configure(quantum=int(rng.integers(2, 20)) * n,
-                coalesce=int(rng.choice([1, 4, 8, -2, -4, -8])))  # negative: in-place spans held back unconditionally
+                coalesce=int(rng.choice([1, 4, 8, 16, -2, -4, -8, -16])))  # negative: in-place spans held back unconditionally
     refs = [ora.PsdCascade(n, "f64") for _ in range(nch)]
     pos = [0] * nch
     detrends = ["none", "midpoint", "span", "mean"]
