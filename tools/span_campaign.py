@@ -22,7 +22,7 @@ for seed in range(first, first + count):
     n = sizes[seed % len(sizes)]
     detrend = ["none", "mean"][int(rng.integers(0, 2))]
     avg = None if rng.random() < 0.6 else (int(rng.integers(1, 60)), int(rng.integers(1, 3000)))
-    nspans = int(rng.integers(1, 8))
+    nspans = int(rng.integers(1, 8)) if rng.random() < 0.6 else int(rng.integers(8, 24))
     lens = []
     for _ in range(nspans):
         r = rng.random()
@@ -40,7 +40,7 @@ for seed in range(first, first + count):
     torch.cuda.synchronize()
     try:
         g = pkg.PsdCascadeBank(n)
-        co = int(rng.choice([1, 4, -2, -3, -4, -8]))  # negative: spans are held back even on an idle device
+        co = int(rng.choice([1, 4, 16, -2, -3, -4, -8, -11, -16]))  # negative: spans are held back even on an idle device
         g.configure(coalesce=co)
         g.set_detrend(pkg.Detrend[detrend.upper()])
         if avg:
