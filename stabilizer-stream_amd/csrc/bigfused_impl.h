@@ -30,8 +30,8 @@ struct BigGeo : FusedDec<N> {
     static_assert(THREADS >= FusedDec<N>::HIST, "one carried filter-state element per thread at most");
 };
 
-// DETREND / EWMA as in fused.hip.  Built for two wavefronts per SIMD (the global window / twiddle
-// loads are hoisted early and need the registers).
+// DETREND / EWMA as in fused.hip.  Built for four wavefronts per SIMD (two at N = 16384, whose one
+// workgroup per CU is all the LDS holds).
 template <int N, int DETREND, bool EWMA>
 __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_kernel(const FusedBatch batch,
                                                                          const float *__restrict__ win,
@@ -173,16 +173,15 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
     auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, bool more,
                          float *o, int p) {
-        // The window and twiddle tables are the same for every pair, and the compiler keeps all of a
-        // lane's entries (8 + 30 + 16 registers) live across the whole run.  With one lane per thread
-        // that fits the 256 registers of two wavefronts per SIMD and is the fastest arrangement
-        // (measured: re-loading per pair costs 2-5 % even at twice the occupancy); with two lanes per
-        // thread it does not fit, so there the table pointers are re-derived per pair, which keeps the
-        // loads inside the pair (L1 / L2 hits).
+        // The window and twiddle tables are the same for every pair, and left alone the compiler hoists the
+        // loads and keeps all of a lane's entries (8 + 30 + 16 registers) live across the whole run -- which pins
+        // the kernels to two wavefronts per SIMD (or spills, with two lanes per thread).  The table pointers are
+        // re-derived per pair instead, so the loads stay inside the pair (L1 / L2 hits) and the kernels fit the
+        // 128 registers of four wavefronts per SIMD with a few dwords spilled: +10 % (N = 4096) to +22 % (N = 8192)
+        // at steady state.  (A first, cold measurement had this 2-5 % slower)
         const cf *tw0p = tw0g, *twap = twag;
         const float *winp = win;
-        if constexpr (VT > 1)
-            asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
+        asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(3);

@@ -110,7 +110,7 @@ struct FusedBatch {
 #define PSDK_FUSED_WPS 4
 #endif
 #ifndef PSDK_BIG_WPS
-#define PSDK_BIG_WPS 2
+#define PSDK_BIG_WPS 4
 #endif
 constexpr int BIG_WAVES_PER_SIMD = PSDK_BIG_WPS;     // N = 2048 ... 8192 kernels: wavefronts per SIMD they are built for
 constexpr int FUSED_WAVES = PSDK_FUSED_WAVES;        // wavefronts per workgroup
