@@ -3,10 +3,10 @@
 // half-band decimation of the same samples), with a whole workgroup as the team: the
 // (4, RA, RB, 16) FFT of fft_block.h over N/16 "lanes" of 16 elements, hand-offs by workgroup
 // barriers, window and the two large twiddle tables read from global memory (L2 resident), the
-// small one in LDS.  A thread plays VT lanes (tl = thread + THREADS v): VT = 1 up to N = 8192;
-// N = 16384 uses VT = 2, i.e. 512 threads with 32 elements each -- its 1024-lane team as 1024
-// threads would be capped at 128 VGPRs (16 wavefronts on one CU) and spilled ~450 bytes per lane.
-// Each bigfused_<N>.hip instantiates one size.
+// small one in LDS.  A thread plays VT lanes (tl = thread + THREADS v).  VT = 1 everywhere now; VT = 2
+// (512 threads with 32 elements each) was how N = 16384 fitted while the table loads were hoisted out of the
+// pair loop -- 1024 threads are capped at 128 VGPRs (16 wavefronts on one CU) and spilled ~450 bytes per lane
+// then -- and stays available (-DPSDK_BIG16K_VT=2).  Each bigfused_<N>.hip instantiates one size.
 #pragma once
 #include <hip/hip_ext.h>
 
@@ -19,11 +19,16 @@ template <int N>
 struct BigGeo : FusedDec<N> {
     using T = BlockFft<N>;
     static constexpr int TEAM = T::TEAM;          // lanes of the team
-    static constexpr int VT = N >= 16384 ? 2 : 1; // lanes per thread
+// N = 16384: one lane per thread (1024 threads, four wavefronts per SIMD) now that the tables are not held in
+// registers; 512 threads x 2 lanes (the only way it fitted while they were) reads 14 % lower.
+#ifndef PSDK_BIG16K_VT
+#define PSDK_BIG16K_VT 1
+#endif
+    static constexpr int VT = N >= 16384 ? PSDK_BIG16K_VT : 1; // lanes per thread
     static constexpr int THREADS = TEAM / VT;
     static constexpr int WAVES = THREADS / 64;
     // wavefronts per SIMD the kernel is built for (register budget 512 / WPS) and workgroups per CU
-    static constexpr int WPS = N >= 16384 ? 2 : BIG_WAVES_PER_SIMD;
+    static constexpr int WPS = N >= 16384 ? (PSDK_BIG16K_VT == 2 ? 2 : 4) : BIG_WAVES_PER_SIMD;
     static constexpr int BLOCKS_PER_CU = (4 * WPS / WAVES) > 0 ? (4 * WPS / WAVES) : 1;
     static constexpr int SCR = 2 * T::FRAME;
     static_assert(FusedDec<N>::END <= SCR && FusedDec<N>::WEND <= SCR, "decimator arrays exceed the frame");

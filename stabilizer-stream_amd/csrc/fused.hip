@@ -513,7 +513,7 @@ int fused_max_blocks(int n)
     case 8192:
         return big(512, BIG_WAVES_PER_SIMD); // 70 KB
     case 16384:
-        return 256; // 512 threads x 2 lanes, 139 KB
+        return 256; // 1024 threads, 139 KB of LDS: one per CU
     default:
         return 256 * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES); // 8 wavefronts, <= 80 KB: two per CU
     }
