@@ -123,9 +123,8 @@ struct BlockFft {
             Dft<RB>::run(v + RB * i);
 #pragma unroll
             for (int q = 1; q < RB; ++q)
-                // plain loads as in fft_team.h pass1 (+3-5 %); N = 16384 stays with the single reads (measured
-                // with two lanes per thread, where there were no registers to keep them in flight)
-                v[RB * i + q] = cmul(v[RB * i + q], N >= 16384 ? lds_ld(twb + (q - 1) * 16 + s) : twb[(q - 1) * 16 + s]);
+                // plain loads as in fft_team.h pass1 (+3-5 %; +0.7 % at N = 16384)
+                v[RB * i + q] = cmul(v[RB * i + q], twb[(q - 1) * 16 + s]);
         }
     }
     static PSDK_HD void storeB(int tl, const cf *v, cf *frame)
