@@ -184,9 +184,21 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         // re-derived per pair instead, so the loads stay inside the pair (L1 / L2 hits) and the kernels fit the
         // 128 registers of four wavefronts per SIMD with a few dwords spilled: +10 % (N = 4096) to +22 % (N = 8192)
         // at steady state.  (A first, cold measurement had this 2-5 % slower)
+        // Two ways to do that, measured per size: an opaque zero OFFSET keeps the pointers global (N <= 4096:
+        // +3 % at 4096); pointers that went through the asm themselves are generic to the backend, their flat
+        // loads wait on the LDS counter too and end up later in the schedule, which suits the sizes with more
+        // table registers per lane (N = 8192: +3 %, N = 16384: +6 % over the global form).
         const cf *tw0p = tw0g, *twap = twag;
         const float *winp = win;
-        asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
+        if constexpr (N <= 4096) {
+            size_t zofs = 0;
+            asm volatile("" : "+s"(zofs));
+            tw0p += zofs;
+            twap += zofs;
+            winp += zofs;
+        } else {
+            asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
+        }
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(3);
