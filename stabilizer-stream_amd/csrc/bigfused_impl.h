@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         }
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
             sf[h_pack & 0xFFFFu] = hs[tp];
         // samples -> polyphase arrays as single floats (ds_write2_b32 from the registers the loads

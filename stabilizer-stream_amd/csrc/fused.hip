@@ -253,7 +253,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         // gets its few issue slots at once instead of queueing behind the butterflies of the other
         // wavefronts of the SIMD: +3-4 %)
         PSDK_STAMP(0);
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
 #pragma unroll
         for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)

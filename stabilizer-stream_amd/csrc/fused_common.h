@@ -8,6 +8,10 @@
 #include "hbf_taps.h"
 #include "kernels.h"
 
+#ifndef PSDK_DEC_PRIO
+#define PSDK_DEC_PRIO 3 // wave priority during the decimator stages (0 during the FFT)
+#endif
+
 namespace psdk {
 
 // Decimator arrays inside a team's LDS frame (floats): [history | new], even/odd polyphase,
