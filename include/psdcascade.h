@@ -103,7 +103,12 @@ typedef struct psdc_profile {
  * device `device`.  n: power of two, 16 <= n <= 16384 (the reference takes any
  * N >= 2 with (N - overlap) % 8 == 0, src/psd.rs:138,247; this build ships the
  * fixed power-of-two FFT sizes).  Returns NULL on failure; psdc_last_error(NULL)
- * explains. */
+ * explains.
+ * Which kernels run: the single-pass fused kernels (stream read once: detrend +
+ * window + FFT + |X|^2 + /8 decimator in one launch) exist for the HANN window and
+ * n = 256 ... 16384 -- what the reference's binaries and BASELINE configs use.  The
+ * rectangular window and n < 256 take the generic two-pass kernels (welch +
+ * hbf_dec8: same results, the stream is read twice, about a third of the rate). */
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
 
 /* Drop (src/bin/psd.rs:190 `dec.clear()`). */

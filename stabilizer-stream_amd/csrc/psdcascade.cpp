@@ -1432,7 +1432,7 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
     case PSDC_OPT_COALESCE: {
         const int64_t k = value < 0 ? -value : value; // negative: hold spans back even on an idle device
         if (k < 1 || k > MAX_COALESCE)
-            return fail(h, PSDC_ERR_ARG, "coalesce out of range (1..8)");
+            return fail(h, PSDC_ERR_ARG, "coalesce out of range (1..16)");
         int rc = flush_all(h);
         if (rc)
             return rc;
