@@ -6,11 +6,23 @@
  * The reference (src/psd.rs:2,246-253) takes its decimator from the crates.io
  * dependency idsp 0.20.0 (Cargo.lock:1365-1366), `idsp::hbf::HBF_DEC_CASCADE`,
  * whose source is NOT present under /root/reference (not vendored, no network).
- * The values below are the published idsp `HBF_TAPS` table restated from
- * memory of the public crate source (idsp `src/hbf.rs`: "2*signal.remez(4*n-1,
- * bands=(0,.5-df/2,.5+df/2,1), desired=(1,0), fs=2, grid_density=512)[:2*n:2]",
- * >98 dB stop band, 0.4 pass band).  They could not be diffed against the crate
- * in this container: PARITY UNPINNED for exact decimator sample values.
+ * The values below are the published idsp `HBF_TAPS` rows.  They are DERIVED, not
+ * recalled: idsp documents the design recipe of its table (src/hbf.rs:
+ * "2*signal.remez(4*n-1, bands=(0,.5-df/2,.5+df/2,1), desired=(1,0), fs=2,
+ * grid_density=512)[:2*n:2]", df = 0.2 / 0.47 / 0.754 for n = 15 / 6 / 3);
+ * tests/golden/derive_hbf_taps.py runs it with scipy, commits the result as
+ * tests/golden/hbf_taps_derived.json, and tests/test_hbf_taps.py holds this table
+ * and the product's (csrc/hbf_taps.h) to it (<= 1e-8 per tap; bit-identical to
+ * each other as f32).  idsp's taps are f32 constants: both oracle instantiations
+ * round the rows to f32 first and widen that (psd_oracle_impl.h, hbf2_init).
+ *
+ * What stays unverifiable without the crate (idsp 0.20.0 is not vendored and there
+ * is no network): that `HBF_DEC_CASCADE.inner.1.inner.1` (src/psd.rs:248-253)
+ * selects exactly these three rows in this order, the summation order inside
+ * idsp's FIR kernel (last-bit differences per output), and the VALUE of
+ * hbf_dec_response_length(3) = 35 (src/psd.rs:149; the reference pins only the
+ * length relation at :622).  Exact decimator sample parity vs the crate is
+ * therefore still unpinned; the TAPS are pinned to idsp's published algorithm.
  *
  * What the reference itself pins, and this table satisfies (tests/test_oracle_*):
  *   - each unique-tap row sums to 0.5 => odd branch DC gain 1, centre tap 1,

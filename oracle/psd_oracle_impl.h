@@ -197,7 +197,7 @@ static void SFX(hbf2_init)(SFX(ora_hbf2) * h, int m, const double *taps)
     memset(h, 0, sizeof(*h));
     h->m = m;
     for (int i = 0; i < m; ++i)
-        h->taps[i] = (REAL)taps[i];
+        h->taps[i] = (REAL)(float)taps[i]; /* idsp's HBF_TAPS are f32 constants: round, then widen */
 }
 
 /* Block form: x holds 2k samples, y receives k; e/o are scratch of at least

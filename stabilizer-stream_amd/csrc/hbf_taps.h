@@ -2,8 +2,11 @@
 // last three /2 stages of idsp::hbf::HBF_DEC_CASCADE, idsp 0.20.0).
 //
 // idsp is a crates.io dependency of the reference and is not vendored under
-// /root/reference; the numbers are the published idsp HBF_TAPS rows restated
-// here (each unique-tap row sums to 0.5: centre tap 1, stage DC gain 2).
+// /root/reference; the numbers are the published idsp HBF_TAPS rows, derived from the
+// design recipe idsp documents (remez, df = 0.754 / 0.47 / 0.2 for 3 / 6 / 15 unique
+// taps): tests/golden/derive_hbf_taps.py regenerates them, tests/test_hbf_taps.py holds
+// this table to the derivation (<= 1e-8 per tap) and to the oracle's table bit for bit.
+// Each unique-tap row sums to 0.5 (centre tap 1, stage DC gain 2).
 // ONE swappable table: replace these rows (and oracle/hbf_taps_oracle.h, then
 // regenerate tests/golden) if the crate's table differs -- no code change.
 //
