@@ -47,19 +47,26 @@ def gpu_required():
         pytest.fail("test marked gpu but no HIP device is visible")
 
 
-# Tolerance of every PSD parity check (BASELINE.json: "PSD within 1e-5 relative of
-# the CPU reference"):
-#   |gpu - ref| <= RTOL*ref + ATOL_FRAC*mean(ref) + DYN*sqrt(ref*max(ref)).
-# ATOL_FRAC only matters for bins that a detrend nulls (e.g. DC under Detrend::Mean).
-# DYN is the dynamic-range floor of ANY f32 FFT (the reference's rustfft included): a
-# bin's amplitude carries an error of ~1e-7 of the largest component of the frame, so a
-# bin 40 dB below a strong tone cannot be known to 1e-5 in power from f32 arithmetic.
+# Tolerance of the PSD parity checks (BASELINE.json: "PSD within 1e-5 relative of the CPU reference").
+#
+# PURE:   |gpu - ref| <= RTOL * ref on every bin.  Asserted wherever the spectrum is white noise with enough
+#         averages (the headline path): nothing but the stated 1e-5.
+# WIDENED (signals with a strong tone / DC level, nulled bins, stages with one or two segments):
+#         |gpu - ref| <= RTOL*ref + ATOL_FRAC*mean(ref) + DYN*sqrt(ref*max(ref)).
+#         DYN is the dynamic-range floor of ANY f32 FFT (the reference's rustfft included): a bin's amplitude
+#         carries an error of ~1e-7 of the largest component of the frame, so a bin 40 dB below a strong tone
+#         cannot be known to 1e-5 in power from f32 arithmetic; ATOL_FRAC only matters for bins that a detrend
+#         nulls (e.g. DC under Detrend::Mean).  The widening is not taken on trust: when the f32 oracle's result
+#         (the reference's own arithmetic, oracle *_f32) is passed as `ref_f32`, the bins whose tolerance the
+#         extra terms more than double must show a GPU error (rms over those bins) no larger than the f32
+#         reference's own -- or meet the pure 1e-5 there in the rms sense.
 RTOL = 1e-5
 ATOL_FRAC = 1e-6
 DYN = 5e-7
+WORST = {"pure": 0.0, "widened": 0.0}  # worst pure-relative error seen per kind (printed at session end)
 
 
-def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN):
+def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN, pure=False, ref_f32=None):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
@@ -68,15 +75,40 @@ def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN)
     # a stage with count 0 included by min_count = 0 reads 0 * (1/0) = NaN, in the reference too
     both_nan = np.isnan(got) & np.isnan(ref)
     assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
-    got, ref = got[~both_nan], ref[~both_nan]
+    keep = ~both_nan
+    got, ref = got[keep], ref[keep]
     if ref.size == 0:
         return 0.0
-    tol = rtol * np.abs(ref) + atol_frac * np.mean(np.abs(ref)) + dyn * np.sqrt(np.abs(ref) * np.max(np.abs(ref)))
+    base = rtol * np.abs(ref)
+    if pure:
+        tol = base
+    else:
+        tol = base + atol_frac * np.mean(np.abs(ref)) + dyn * np.sqrt(np.abs(ref) * np.max(np.abs(ref)))
     err = np.abs(got - ref)
-    worst = int(np.argmax(err / tol))
+    worst = int(np.argmax(err / np.maximum(tol, 1e-300)))
     assert np.all(err <= tol), (f"{what}: bin {worst} got {got[worst]:.9g} ref {ref[worst]:.9g} "
-                                f"err/tol {err[worst] / tol[worst]:.3g}")
-    return float(np.max(err / np.maximum(np.abs(ref), 1e-300)))
+                                f"err/tol {err[worst] / tol[worst]:.3g} ({'pure 1e-5' if pure else 'widened'})")
+    rel = float(np.max(err / np.maximum(np.abs(ref), 1e-300)))
+    if not pure and ref_f32 is not None:
+        wide = tol > 2.0 * base  # the bins that lean on the extra terms
+        if np.any(wide):
+            e32 = np.abs(np.asarray(ref_f32, dtype=np.float64)[keep] - ref)
+            rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+            g, r, p = rms(err[wide]), rms(e32[wide]), rms(base[wide])
+            assert g <= max(r, p), (f"{what}: on the {int(wide.sum())} widened bins the GPU's rms error {g:.3g} exceeds both the "
+                                    f"f32 reference arithmetic's {r:.3g} and the pure 1e-5 level {p:.3g}")
+        # worst pure-relative error over the bins that do NOT lean on the widening
+        if np.any(~wide):
+            rel = float(np.max(err[~wide] / np.maximum(np.abs(ref[~wide]), 1e-300)))
+    WORST["pure" if pure else "widened"] = max(WORST["pure" if pure else "widened"], rel)
+    return rel
+
+
+def pytest_terminal_summary(terminalreporter):
+    if WORST["pure"] or WORST["widened"]:
+        terminalreporter.write_line(
+            f"PSD parity: worst relative error under the pure 1e-5 assertion {WORST['pure']:.3g}; "
+            f"worst on non-widened bins of the widened assertions {WORST['widened']:.3g}")
 
 
 def assert_psd_close_anchored(got, ref, n, count, xmax, what=""):
