@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PSDC_ABI_VERSION 1
+#define PSDC_ABI_VERSION 2
 
 /* status codes */
 #define PSDC_OK 0
@@ -84,7 +84,8 @@ typedef struct psdc_break {
 
 /* PsdStage accessors (src/psd.rs:271-287) + Break bookkeeping in one record */
 typedef struct psdc_stage_stat {
-    uint32_t count; /* PsdStage::count  src/psd.rs:275-277 */
+    uint32_t count; /* PsdStage::count  src/psd.rs:275-277; saturates at u32::MAX where the reference's
+                     * u32 wraps after 2^32 segments (the library counts in 64 bits; gain() follows that) */
     uint32_t avg;   /* Psd::avg         src/psd.rs:133 */
     uint64_t pending;   /* PsdStage::buf().len()  src/psd.rs:285-287 */
     uint64_t processed; /* src/psd.rs:511-512 */
@@ -141,9 +142,27 @@ int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count);
 int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len);
 
 /* Same, but `d_x` is device memory on the handle's device and is read in place
- * (no staging copy).  The work is enqueued asynchronously: `d_x` must stay
- * valid and unmodified until psdc_sync()/any read-out returns. */
+ * (no staging copy).  The work is enqueued asynchronously on the handle's own stream, possibly
+ * after this call returns (PSDC_OPT_COALESCE): whatever produced `d_x` must have COMPLETED before
+ * the call (host-synchronised; or use psdc_process_device_after), and `d_x` must stay valid and
+ * unmodified until psdc_sync()/any read-out returns or a psdc_record_consumed event completes. */
 int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size_t len);
+
+/* psdc_process_device for a producer that runs on ANOTHER HIP stream (a decode kernel, torch's
+ * current stream, ...).  The handle works on a private non-blocking stream and, with
+ * PSDC_OPT_COALESCE, may not even have enqueued the kernels that read `d_x` when the call
+ * returns, so plain psdc_process_device requires that the producer has FINISHED (host-synchronised)
+ * before the call.  Here `producer_event` -- a hipEvent_t the caller recorded behind the work that
+ * writes d_x, passed as void*; NULL = none -- is waited for on the device by the handle's stream
+ * before anything reads the span: no host synchronisation. */
+int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x, size_t len,
+                              void *producer_event);
+
+/* The other direction: enqueue everything held so far and record `consumed_event` (hipEvent_t as
+ * void*) on the handle's stream.  When it has completed, every span handed to psdc_process_device*
+ * before this call has been read for the last time and its memory may be overwritten (the producer
+ * waits for it with hipStreamWaitEvent).  Does not wait on the host. */
+int psdc_record_consumed(psdc_handle *h, void *consumed_event);
 
 /* Frame::from_bytes + AdcDac::traces (src/de/frame.rs:49-60, src/de/data.rs:11-82)
  * + process() of the four traces ADC0, ADC1, DAC0, DAC1 into channels 0..3
@@ -208,6 +227,40 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
 /* PsdCascade::rbw (src/psd.rs:427-429). */
 float psdc_rbw(const psdc_handle *h);
 
+/* ---- Psd<N>: one stage (src/psd.rs:122-288) ------------------------------ */
+
+/* `Psd<N>` with its `PsdStage` trait (src/psd.rs:163-193), the type the reference's own test
+ * drives directly (src/psd.rs:615-632).  Same kernels as the cascade: one stage analyses the
+ * stream, and the /8-decimated stream it emits is handed back instead of feeding a next stage. */
+typedef struct psdc_stage psdc_stage;
+
+/* Psd::new(fft, win) (src/psd.rs:137-152): the FFT plan is the library's own (n as in psdc_create),
+ * window_kind one of PSDC_WINDOW_*; detrend None, avg = u32::MAX, drain = hbf_dec_response_length(3). */
+psdc_stage *psdc_stage_create(uint32_t n, int window_kind, int device);
+void psdc_stage_destroy(psdc_stage *s);
+psdc_stage *psdc_stage_clone(psdc_stage *s); /* #[derive(Clone)] src/psd.rs:122 */
+int psdc_stage_set_avg(psdc_stage *s, uint32_t avg);             /* Psd::set_avg      src/psd.rs:154-156 */
+int psdc_stage_set_detrend(psdc_stage *s, int detrend_kind);      /* Psd::set_detrend  src/psd.rs:158-160 */
+
+/* PsdStage::process(x, y) -> &mut y[..n] (src/psd.rs:196-269): buffers x, completes every full
+ * segment (detrend, window, FFT, accumulate), decimates the samples new to each segment by 8 and
+ * writes the outputs -- minus the one-time drain of hbf_dec_response_length(3) -- to y; *n_out is
+ * the length of the returned slice.  It depends only on the samples fed so far: after T samples in
+ * total, (N + (J-1)(N-overlap))/8 - 35 outputs have been returned, J the segments completed.  cap <
+ * that many new outputs fails with PSDC_ERR_CAPACITY where the reference panics on the slice index
+ * (src/psd.rs:253).  x and y are host memory. */
+int psdc_stage_process(psdc_stage *s, const float *x, size_t len, float *y, size_t cap, size_t *n_out);
+
+/* The same with x and y in device memory (y complete and x free to reuse on return). */
+int psdc_stage_process_device(psdc_stage *s, const float *d_x, size_t len, float *d_y, size_t cap,
+                              size_t *n_out);
+
+int psdc_stage_get_spectrum(psdc_stage *s, float *out /* n/2+1 */); /* PsdStage::spectrum src/psd.rs:271-273 */
+int psdc_stage_get_count(psdc_stage *s, uint32_t *count);           /* PsdStage::count    src/psd.rs:275-277 */
+int psdc_stage_get_gain(psdc_stage *s, float *gain);                /* PsdStage::gain     src/psd.rs:279-283 */
+int psdc_stage_get_buf(psdc_stage *s, float *out, size_t cap, size_t *len); /* PsdStage::buf src/psd.rs:285-287 */
+const char *psdc_stage_last_error(const psdc_stage *s);
+
 /* ---- pure host helpers (no device needed) -------------------------------- */
 
 /* Break::frequencies (src/psd.rs:315-327).  Returns the number written, or the
@@ -237,6 +290,16 @@ int psdc_plan_counts(uint32_t n, int window_kind, uint64_t total, uint32_t cap,
 /* Var::eval (src/var.rs:26-45) on a merged PSD (host, f32). */
 float psdc_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const float *phase_psd,
                     const float *frequencies, size_t n, float tau);
+
+/* Trace::plot (src/bin/psd.rs:125-157) on a merged PSD: the Trapezoidal integrator for irregular
+ * sampling (src/bin/psd.rs:98-116) runs over (frequencies[i], psd[i]); *rms = sqrt of the integral over
+ * the bins with integral_start <= fs * f <= integral_end (no interpolation at the limits, like the
+ * reference); the plot points -- for every bin whose f is a normal float -- are
+ * x = log10(f) + log10(fs), y = integrate ? sqrt(running integral) : 10 (log10(p) - log10(fs)), written
+ * as pairs of doubles to plot_xy (room for plot_cap points; NULL to skip).  Host, f32 like the reference. */
+int psdc_trace_plot(const float *psd, const float *frequencies, size_t n, float fs, int integrate,
+                    float integral_start, float integral_end, float *rms, double *plot_xy,
+                    size_t plot_cap, size_t *n_points);
 
 /* ---- device utilities ---------------------------------------------------- */
 

@@ -84,6 +84,8 @@ def _declare(L):
     L.ora_frequencies.argtypes = [C.POINTER(Break), i32, fp]
     L.ora_var_eval.restype = C.c_float
     L.ora_var_eval.argtypes = [i32, i32, C.c_float, sz, fp, fp, sz, C.c_float]
+    L.ora_trace_plot.restype = C.c_long
+    L.ora_trace_plot.argtypes = [fp, fp, sz, C.c_float, i32, C.c_float, C.c_float, fp, dp]
     L.ora_adcdac_decode.restype = i32
     L.ora_adcdac_decode.argtypes = [C.POINTER(C.c_uint8), sz, fp, fp, fp, fp,
                                     C.POINTER(u32), C.POINTER(u32)]
@@ -264,6 +266,17 @@ def var_eval(phase_psd, frequencies, tau, x_exp=-2, sinx_exp=4, clip=3.402823466
     f = np.ascontiguousarray(frequencies, dtype=np.float32)
     return float(lib().ora_var_eval(x_exp, sinx_exp, clip, dc_cut, _ptr(p, C.c_float),
                                     _ptr(f, C.c_float), p.size, tau))
+
+
+def trace_plot(psd, frequencies, fs=1.0, integrate=False, integral_start=0.0, integral_end=float("inf")):
+    """Trace::plot (src/bin/psd.rs:125-157): (rms, plot points)."""
+    p = np.ascontiguousarray(psd, dtype=np.float32)
+    f = np.ascontiguousarray(frequencies, dtype=np.float32)
+    xy = np.empty((max(1, p.size), 2), dtype=np.float64)
+    rms = C.c_float()
+    m = lib().ora_trace_plot(_ptr(p, C.c_float), _ptr(f, C.c_float), p.size, fs, int(integrate), integral_start,
+                             integral_end, C.byref(rms), _ptr(xy, C.c_double))
+    return rms.value, xy[:m].copy()
 
 
 def adcdac_decode(frame):

@@ -125,6 +125,45 @@ float ora_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const flo
     return accu;
 }
 
+/* ---- Trace::plot + Trapezoidal (src/bin/psd.rs:98-116, :125-157), f32 like the reference.
+ * Returns the number of plot points; *rms = sqrt(pi) (:156); plot_xy (may be NULL) gets
+ * [log10(f) + log10(fs), integrate ? sqrt(p0.get()) : 10 (log10(p) - log10(fs))] per normal f. */
+struct ora_trapezoidal {
+    float x, y, i; /* :98-102, Default: zeros */
+};
+static float ora_trapezoidal_push(struct ora_trapezoidal *t, float x, float y)
+{
+    const float di = (y + t->y) * 0.5f * (x - t->x); /* :106 */
+    t->x = x;                                        /* :107 */
+    t->y = y;                                        /* :108 */
+    t->i += di;                                      /* :109 */
+    return di;
+}
+long ora_trace_plot(const float *psd, const float *frequencies, size_t n, float fs, int integrate,
+                    float integral_start, float integral_end, float *rms, double *plot_xy)
+{
+    const float logfs = log10f(fs); /* :127 */
+    struct ora_trapezoidal p0 = {0.0f, 0.0f, 0.0f};
+    float pi = 0.0f;
+    long np = 0;
+    for (size_t k = 0; k < n; ++k) { /* psd.iter().zip(frequencies.iter()) :131-134 */
+        const float p = psd[k], f = frequencies[k];
+        const float dp = ora_trapezoidal_push(&p0, f, p); /* :136 */
+        const float hz = fs * f;
+        if (integral_start <= hz && hz <= integral_end) /* (start..=end).contains :137 */
+            pi += dp;
+        if (isnormal(f)) { /* :141 */
+            if (plot_xy) {
+                plot_xy[2 * np] = (double)(log10f(f) + logfs);                                          /* :143 */
+                plot_xy[2 * np + 1] = (double)(integrate ? sqrtf(p0.i) : 10.0f * (log10f(p) - logfs)); /* :144-148 */
+            }
+            ++np;
+        }
+    }
+    *rms = sqrtf(pi);
+    return np;
+}
+
 /* ---- AdcDac frame decode (src/de/frame.rs:5-37,49-60; src/de/data.rs:11-82)
  * returns 0 ok; -1 InvalidHeader; -2 UnknownFormat; -3 PayloadSize;
  * -4 would panic in the reference (len<8, or len/64 != batches); -5 other format.

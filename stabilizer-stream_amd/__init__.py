@@ -198,6 +198,8 @@ def lib():
     f("psdc_set_avg", i32, [H, u32, u32])
     f("psdc_process", i32, [H, u32, fp, sz])
     f("psdc_process_device", i32, [H, u32, C.c_void_p, sz])
+    f("psdc_process_device_after", i32, [H, u32, C.c_void_p, sz, C.c_void_p])
+    f("psdc_record_consumed", i32, [H, C.c_void_p])
     f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_loss_read", i32, [H, C.POINTER(_CLoss), i32])
     f("psdc_flush", i32, [H])
@@ -220,6 +222,20 @@ def lib():
     f("psdc_hbf_dec8", i32, [i32, fp, sz, fp])
     f("psdc_fill_noise_device", i32, [i32, C.c_void_p, sz, u64, u64])
     f("psdc_profile_read", i32, [H, C.POINTER(_CProfile), i32])
+    f("psdc_trace_plot", i32, [fp, fp, sz, C.c_float, i32, C.c_float, C.c_float, fp, C.POINTER(C.c_double), sz,
+                               C.POINTER(sz)])
+    f("psdc_stage_create", H, [u32, i32, i32])
+    f("psdc_stage_destroy", None, [H])
+    f("psdc_stage_clone", H, [H])
+    f("psdc_stage_set_avg", i32, [H, u32])
+    f("psdc_stage_set_detrend", i32, [H, i32])
+    f("psdc_stage_process", i32, [H, fp, sz, fp, sz, C.POINTER(sz)])
+    f("psdc_stage_process_device", i32, [H, C.c_void_p, sz, C.c_void_p, sz, C.POINTER(sz)])
+    f("psdc_stage_get_spectrum", i32, [H, fp])
+    f("psdc_stage_get_count", i32, [H, C.POINTER(u32)])
+    f("psdc_stage_get_gain", i32, [H, fp])
+    f("psdc_stage_get_buf", i32, [H, fp, sz, C.POINTER(sz)])
+    f("psdc_stage_last_error", C.c_char_p, [H])
     _lib = L
     return L
 
@@ -231,6 +247,10 @@ EXPORTS = [
     "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_read_channel", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
+    "psdc_process_device_after", "psdc_record_consumed", "psdc_trace_plot",
+    "psdc_stage_create", "psdc_stage_destroy", "psdc_stage_clone", "psdc_stage_set_avg", "psdc_stage_set_detrend",
+    "psdc_stage_process", "psdc_stage_process_device", "psdc_stage_get_spectrum", "psdc_stage_get_count",
+    "psdc_stage_get_gain", "psdc_stage_get_buf", "psdc_stage_last_error",
 ]
 
 
@@ -297,9 +317,18 @@ class PsdCascadeBank:
         x = np.ascontiguousarray(x, dtype=np.float32)
         self._ck(self._L.psdc_process(self._h, channel, _fptr(x), x.size))
 
-    def process_device(self, channel, ptr, length):
-        """ptr: device address (e.g. torch tensor .data_ptr()) of `length` f32 samples."""
-        self._ck(self._L.psdc_process_device(self._h, channel, C.c_void_p(ptr), length))
+    def process_device(self, channel, ptr, length, after=None):
+        """ptr: device address (e.g. torch tensor .data_ptr()) of `length` f32 samples.  The producer of the
+        samples must have completed -- or pass `after`: a hipEvent_t handle (torch.cuda.Event.cuda_event)
+        recorded behind the producing work; the library's stream then waits for it on the device."""
+        if after is None:
+            self._ck(self._L.psdc_process_device(self._h, channel, C.c_void_p(ptr), length))
+        else:
+            self._ck(self._L.psdc_process_device_after(self._h, channel, C.c_void_p(ptr), length, C.c_void_p(after)))
+
+    def record_consumed(self, event):
+        """Record the hipEvent_t handle `event` behind the last read of every span handed over so far."""
+        self._ck(self._L.psdc_record_consumed(self._h, C.c_void_p(event)))
 
     def process_adcdac_frames(self, data, frame_size):
         """data: bytes-like holding whole frames; returns the number of frames ingested."""
@@ -399,8 +428,8 @@ class PsdCascade:
     def process(self, x):
         self._b.process(0, x)
 
-    def process_device(self, ptr, length):
-        self._b.process_device(0, ptr, length)
+    def process_device(self, ptr, length, after=None):
+        self._b.process_device(0, ptr, length, after)
 
     def psd(self, opts=MergeOpts()):
         return self._b.psd(0, opts)
@@ -432,6 +461,86 @@ class PsdCascade:
 
     def close(self):
         self._b.close()
+
+
+class Psd:
+    """One stage: `Psd<N>` with the `PsdStage` trait (src/psd.rs:122-288).
+
+        s = Psd(512)                     Psd::<N>::new(fft, Arc::new(Window::hann()))   src/psd.rs:137
+        y = s.process(x)                 PsdStage::process(&x, &mut y) -> &mut y[..n]   src/psd.rs:196-269
+        s.spectrum(), s.gain(), s.count(), s.buf()                                      src/psd.rs:271-287
+    """
+
+    def __init__(self, n, window=Window.HANN, device=0, _handle=None):
+        self.n, self.window, self.device = n, Window(window), device
+        self._L = lib()
+        self._s = _handle if _handle is not None else self._L.psdc_stage_create(n, int(window), device)
+        if not self._s:
+            _raise(ERR_DEVICE)
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.psdc_stage_destroy(self._s)
+            self._s = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc < 0:
+            msg = self._L.psdc_stage_last_error(self._s)
+            raise PsdError(rc, msg.decode() if msg else "")
+        return rc
+
+    def clone(self):
+        h = self._L.psdc_stage_clone(self._s)
+        if not h:
+            _raise(ERR_DEVICE)
+        return Psd(self.n, self.window, self.device, _handle=h)
+
+    def set_avg(self, avg):
+        self._ck(self._L.psdc_stage_set_avg(self._s, avg))
+
+    def set_detrend(self, d):
+        self._ck(self._L.psdc_stage_set_detrend(self._s, int(d)))
+
+    def process(self, x, y=None):
+        """Returns the written prefix of y (allocated with x.len()/8 + N/8 items when not given)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if y is None:
+            y = np.empty(x.size // 8 + self.n // 8, dtype=np.float32)
+        assert y.dtype == np.float32 and y.flags.c_contiguous
+        m = C.c_size_t()
+        self._ck(self._L.psdc_stage_process(self._s, _fptr(x), x.size, _fptr(y), y.size, C.byref(m)))
+        return y[:m.value]
+
+    def process_device(self, x_ptr, length, y_ptr, cap):
+        m = C.c_size_t()
+        self._ck(self._L.psdc_stage_process_device(self._s, C.c_void_p(x_ptr), length, C.c_void_p(y_ptr), cap,
+                                                   C.byref(m)))
+        return m.value
+
+    def spectrum(self):
+        out = np.empty(self.n // 2 + 1, dtype=np.float32)
+        self._ck(self._L.psdc_stage_get_spectrum(self._s, _fptr(out)))
+        return out
+
+    def count(self):
+        c = C.c_uint32()
+        self._ck(self._L.psdc_stage_get_count(self._s, C.byref(c)))
+        return c.value
+
+    def gain(self):
+        g = C.c_float()
+        self._ck(self._L.psdc_stage_get_gain(self._s, C.byref(g)))
+        return g.value
+
+    def buf(self):
+        ln = C.c_size_t()
+        self._ck(self._L.psdc_stage_get_buf(self._s, None, 0, C.byref(ln)))
+        out = np.empty(ln.value, dtype=np.float32)
+        if ln.value:
+            self._ck(self._L.psdc_stage_get_buf(self._s, _fptr(out), out.size, C.byref(ln)))
+        return out
 
 
 # ---- pure host helpers (no device) -----------------------------------------
@@ -476,6 +585,21 @@ def var_eval(phase_psd, frequencies, tau, x_exp=-2, sinx_exp=4, clip=3.402823466
     p = np.ascontiguousarray(phase_psd, dtype=np.float32)
     f = np.ascontiguousarray(frequencies, dtype=np.float32)
     return float(lib().psdc_var_eval(x_exp, sinx_exp, clip, dc_cut, _fptr(p), _fptr(f), p.size, tau))
+
+
+def trace_plot(psd, frequencies, fs=1.0, integrate=False, integral_start=0.0, integral_end=float("inf"), plot=True):
+    """Trace::plot (src/bin/psd.rs:125-157): (integrated rms over [integral_start, integral_end] Hz, plot points)."""
+    p = np.ascontiguousarray(psd, dtype=np.float32)
+    f = np.ascontiguousarray(frequencies, dtype=np.float32)
+    assert p.size == f.size
+    rms, npts = C.c_float(), C.c_size_t()
+    xy = np.empty((max(1, p.size), 2), dtype=np.float64)
+    rc = lib().psdc_trace_plot(_fptr(p), _fptr(f), p.size, fs, int(integrate), integral_start, integral_end,
+                               C.byref(rms), xy.ctypes.data_as(C.POINTER(C.c_double)) if plot else None, p.size,
+                               C.byref(npts))
+    if rc < 0:
+        _raise(rc)
+    return rms.value, (xy[:npts.value].copy() if plot else None)
 
 
 def hbf_dec8(x, device=0):

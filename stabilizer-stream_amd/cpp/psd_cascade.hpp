@@ -53,6 +53,105 @@ struct Break { // src/psd.rs:290-337
     }
 };
 
+enum class Window : int { Rectangular = 0, Hann = 1 }; // Window::rectangular / Window::hann (src/psd.rs:24-55)
+
+// Psd<N> with the PsdStage trait (src/psd.rs:122-288): one stage, the decimated stream handed back.
+template <size_t N>
+class Psd {
+public:
+    explicit Psd(Window w = Window::Hann, int device = 0) : s_(psdc_stage_create(N, static_cast<int>(w), device))
+    {
+        if (!s_)
+            throw std::runtime_error(psdc_last_error(nullptr));
+    }
+    Psd(const Psd &o) : s_(psdc_stage_clone(o.s_))
+    {
+        if (!s_)
+            throw std::runtime_error(psdc_last_error(nullptr));
+    }
+    Psd(Psd &&o) noexcept : s_(std::exchange(o.s_, nullptr)) {}
+    Psd &operator=(Psd o) noexcept
+    {
+        std::swap(s_, o.s_);
+        return *this;
+    }
+    ~Psd() { psdc_stage_destroy(s_); }
+
+    void set_avg(uint32_t avg) { check(psdc_stage_set_avg(s_, avg)); }
+    void set_detrend(Detrend d) { check(psdc_stage_set_detrend(s_, static_cast<int>(d))); }
+    // PsdStage::process(x, y) -> &mut y[..n] (src/psd.rs:196-269)
+    std::span<float> process(std::span<const float> x, std::span<float> y)
+    {
+        size_t n = 0;
+        check(psdc_stage_process(s_, x.data(), x.size(), y.data(), y.size(), &n));
+        return y.first(n);
+    }
+    std::vector<float> spectrum() const
+    {
+        std::vector<float> p(N / 2 + 1);
+        check(psdc_stage_get_spectrum(s_, p.data()));
+        return p;
+    }
+    float gain() const
+    {
+        float g = 0.0f;
+        check(psdc_stage_get_gain(s_, &g));
+        return g;
+    }
+    uint32_t count() const
+    {
+        uint32_t c = 0;
+        check(psdc_stage_get_count(s_, &c));
+        return c;
+    }
+    std::vector<float> buf() const
+    {
+        size_t len = 0;
+        check(psdc_stage_get_buf(s_, nullptr, 0, &len));
+        std::vector<float> b(len);
+        if (len)
+            check(psdc_stage_get_buf(s_, b.data(), b.size(), &len));
+        return b;
+    }
+
+private:
+    void check(int rc) const
+    {
+        if (rc < 0)
+            throw std::runtime_error(std::string("psdcascade: ") + psdc_stage_last_error(s_));
+    }
+    psdc_stage *s_;
+};
+
+// Var (src/var.rs:4-45) with VarBuilder's defaults; eval on a merged PSD
+struct Var {
+    int x_exp = -2;
+    int sinx_exp = 4;
+    float clip = 3.4028234663852886e38f;
+    size_t dc_cut = 2;
+    float eval(std::span<const float> phase_psd, std::span<const float> frequencies, float tau) const
+    {
+        return psdc_var_eval(x_exp, sinx_exp, clip, dc_cut, phase_psd.data(), frequencies.data(), phase_psd.size(), tau);
+    }
+};
+
+// Trace::plot (src/bin/psd.rs:125-157): integrated rms and plot points of a merged PSD
+inline std::pair<float, std::vector<std::pair<double, double>>> trace_plot(std::span<const float> psd,
+                                                                           std::span<const float> frequencies, float fs,
+                                                                           bool integrate, float integral_start,
+                                                                           float integral_end)
+{
+    std::vector<std::pair<double, double>> pts(psd.size());
+    float rms = 0.0f;
+    size_t np = 0;
+    static_assert(sizeof(std::pair<double, double>) == 2 * sizeof(double));
+    if (psdc_trace_plot(psd.data(), frequencies.data(), psd.size(), fs, integrate, integral_start, integral_end, &rms,
+                        reinterpret_cast<double *>(pts.data()), pts.size(), &np) < 0)
+        throw std::runtime_error(psdc_last_error(nullptr));
+    pts.resize(np);
+    return {rms, std::move(pts)};
+}
+
 template <size_t N>
 class PsdCascade { // src/psd.rs:399-544
 public:

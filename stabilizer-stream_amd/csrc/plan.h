@@ -55,13 +55,21 @@ inline uint32_t stage_avg(uint32_t limit, uint32_t count, unsigned i)
 }
 
 // `count` after nb more segments (src/psd.rs:218-225): saturates at avg + 1.
-inline uint32_t count_after(uint32_t c0, uint32_t avg, uint64_t nb)
+// The reference's count is a u32 that `count += 1` overflows after 2^32 segments when avg = u32::MAX
+// (panic in debug builds, wrap to 0 in release: psd() then drops the stage or divides by a zero gain) --
+// hours on a CPU core, seconds of continuous ingest here.  The library counts in 64 bits: with
+// avg = u32::MAX (plain sum) the count is unbounded and gain() follows it; the u32 the ABI reports
+// saturates at u32::MAX instead of wrapping.  Below 2^32 segments everything is the reference's value.
+inline uint64_t count_after64(uint64_t c0, uint32_t avg, uint64_t nb)
 {
     if (nb == 0)
         return c0;
-    const uint64_t c = std::min<uint64_t>((uint64_t)c0 + nb, (uint64_t)avg + 1);
-    return (uint32_t)c;
+    if (avg == 0xFFFFFFFFu)
+        return c0 + nb;
+    return std::min<uint64_t>(c0 + nb, (uint64_t)avg + 1);
 }
+inline uint32_t count_report(uint64_t c) { return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c; }
+inline uint32_t count_after(uint32_t c0, uint32_t avg, uint64_t nb) { return count_report(count_after64(c0, avg, nb)); }
 
 // EWMA over a batch of nb segments (steps i = 1..nb), src/psd.rs:218-233:
 //   p <- g_i p + s_i,  g_i = avg/count if count > avg else 1.
@@ -88,7 +96,8 @@ inline EwmaPlan plan_ewma(uint32_t c0, uint32_t avg, uint64_t nb)
     const int64_t c1 = (int64_t)std::min(c0, avg) + 1;               // count after step 1
     const int64_t i_sat = (int64_t)avg + 3 - c1;                     // first i with c_{i-1} > avg
     p.i_s = std::max<int64_t>(2, i_sat);
-    p.ewma = (p.g1 != 1.0f) || (p.nb >= p.i_s);
+    // (gamma rounds to 1.0f for avg >= 2^25: every weight is then exactly 1 -- a plain sum)
+    p.ewma = (p.g1 != 1.0f) || (p.nb >= p.i_s && p.gamma != 1.0f);
     const int64_t ng = std::max<int64_t>(0, p.nb - p.i_s + 1);
     double gt = (double)p.g1;
     if (ng > 0)

@@ -48,7 +48,10 @@ struct StageState {
     uint64_t total = 0; // samples received by this stage (absolute end of its stream)
     uint64_t segs = 0;  // segments issued (J)
     uint64_t dec = 0;   // samples handed to the decimator (P)
-    uint32_t count = 0; // PsdStage::count (src/psd.rs:128)
+    uint32_t count = 0; // PsdStage::count (src/psd.rs:128) as reported: count_report(count64)
+    uint64_t count64 = 0; // the count in 64 bits (plan.h count_after64): gain() past 2^32 segments
+    bool sink = false;    // single-stage handles (psdc_stage_*): this stream is handed to the caller, never analysed
+    uint64_t sink_pos = 0; // ... and everything before this absolute index has been handed over
     DevBuf buf;
     float *spectrum = nullptr; // device, n floats (first n/2+1 used, src/psd.rs:127)
 };
@@ -72,6 +75,8 @@ struct Channel {
     // round, which halves / quarters the per-round launch overhead per sample.
     std::vector<DeviceSpan> spans;
     bool has_span() const { return !spans.empty(); }
+    size_t span_max = 0;         // longest in-place span seen
+    bool coalesced_seen = false; // some round of this channel carried more than one span
 };
 
 struct ProfEvents {
@@ -113,6 +118,9 @@ struct psdc_handle {
     bool idle = true;           // nothing ingested since the pipeline was last drained
     float *d_partial = nullptr;
     size_t partial_cap = 0; // floats
+    // stream buffers replaced by larger ones: work already enqueued may still read them, so they are freed
+    // at the next point where the stream is known to be idle (release_retired) -- growing never waits
+    std::vector<float *> retired;
     // epilogue of the last round (fold the partials into the spectra, carry the stream tails),
     // not launched yet: it rides in the first launch of the next round or of a read-out
     std::vector<RedJob> pend_red;
@@ -128,6 +136,7 @@ struct psdc_handle {
     int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
     uint32_t coalesce = 8; // zero-copy spans per channel held back while the device is busy (1 = none)
+    uint32_t stage_limit = MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     bool coalesce_always = false; // hold them back even when the device is idle (tests)
     bool profile = false;
     std::vector<ProfEvents> prof_pending;
@@ -153,6 +162,34 @@ int fail(psdc_handle *h, int code, const std::string &msg)
             return fail(h, PSDC_ERR_DEVICE,                                                      \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
+
+// Every ABI entry runs on the handle's device and leaves the caller's current device as it found it
+// (a caller with several GPUs -- one handle per device, or torch's current device -- must not see it move).
+struct DevScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DevScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            changed = (err == hipSuccess && prev >= 0);
+        }
+    }
+    ~DevScope()
+    {
+        if (changed)
+            (void)hipSetDevice(prev);
+    }
+    DevScope(const DevScope &) = delete;
+    DevScope &operator=(const DevScope &) = delete;
+};
+#define ON_DEVICE(h, dev)                                                                        \
+    DevScope dev_scope_(dev);                                                                    \
+    if (dev_scope_.err != hipSuccess)                                                            \
+        return fail(h, PSDC_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(dev_scope_.err))
 
 // Host samples reach the device through pinned staging buffers.  One core copies ~34 GB/s into
 // pinned memory while the link takes ~55 GB/s, so large copies are split over a few threads
@@ -296,7 +333,7 @@ bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1)) == 0; }
 // release) once count > 2^32 / (N/2): 8.4 M segments at N = 1024 -- hours for the CPU path,
 // about ten seconds of continuous plain-sum ingest here.  The product is widened; below the
 // overflow the value is bit-identical to the reference's.
-float stage_gain(uint32_t n, uint32_t count, float nenbw, float power)
+float stage_gain(uint32_t n, uint64_t count, float nenbw, float power)
 {
     const uint64_t m = (uint64_t)(n / 2u) * count;
     return (float)m * nenbw * power;
@@ -308,6 +345,8 @@ uint32_t cur_stage_avg(const psdc_handle *h, size_t i) { return stage_avg(h->avg
 // next segment and the decimator history
 uint64_t keep_from(const Geometry &g, const StageState &s)
 {
+    if (s.sink)
+        return s.sink_pos;
     if (s.segs == 0)
         return 0;
     const uint64_t back = std::max<uint64_t>(g.overlap, HBF_HALO);
@@ -342,6 +381,7 @@ int add_stage(psdc_handle *h, Channel &c)
     s.buf.p[1] = slot + h->pool_cap;
     s.buf.cap = h->pool_cap;
     s.buf.pooled = true;
+    s.sink = c.st.size() >= h->stage_limit;
     c.st.push_back(s);
     return PSDC_OK;
 }
@@ -414,12 +454,9 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
     if (have && s.buf.p[s.buf.cur])
         HIPCHK(h, hipMemcpyAsync(np[0], s.buf.p[s.buf.cur], sizeof(float) * have,
                                  hipMemcpyDeviceToDevice, h->stream));
-    if (s.buf.p[0] || s.buf.p[1]) {
-        HIPCHK(h, hipStreamSynchronize(h->stream)); // rare: only while buffers grow
-        for (int i = 0; i < 2; ++i)
-            if (s.buf.p[i] && !s.buf.pooled)
-                HIPCHK(h, hipFree(s.buf.p[i]));
-    }
+    for (int i = 0; i < 2; ++i)
+        if (s.buf.p[i] && !s.buf.pooled)
+            h->retired.push_back(s.buf.p[i]); // freed once the stream is idle (release_retired)
     s.buf.p[0] = np[0];
     s.buf.p[1] = np[1];
     s.buf.pooled = false;
@@ -580,6 +617,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         Channel &c = h->ch[ci];
         for (uint32_t k = 0; k < c.st.size(); ++k) {
             StageState &s = c.st[k];
+            if (s.sink)
+                continue; // handed to the caller as it is (psdc_stage_process)
             uint64_t j_new = segments_for(g, s.total);
             // ingest path (all == false): a decimated stage issues whole segment pairs only, the odd
             // segment waits for its partner -- it would cost a launch of the generic kernels every
@@ -672,11 +711,18 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                     return rc;
             }
             StageState &nx = c.st[w.k + 1];
-            // rounds hold 1 ... PSDC_OPT_COALESCE in-place spans: size the next stage's stream for the
-            // largest round the first time it has to grow, not round size by round size
+            // Rounds hold 1 ... PSDC_OPT_COALESCE in-place spans, and stage j sees a round's samples j rounds
+            // later: when a stream has to grow it grows at once to what the LARGEST round will bring it
+            // (longest span seen x the coalescing depth once a round has coalesced, / 8^j), not round size by
+            // round size -- every growth is two allocations and a copy in the middle of a live stream.
             const size_t need = (size_t)(t_next - kf_after(w.c, w.k + 1));
-            const size_t nsp = std::max<size_t>(1, c.spans.size());
-            int rc = ensure_cap(h, nx, need, c.has_span() ? need * h->coalesce / nsp + (size_t)4 * (h->n + HBF_HALO) : 0);
+            size_t grow_to = 0;
+            if (c.span_max) {
+                const uint64_t round_max = (uint64_t)c.span_max * (c.coalesced_seen ? h->coalesce : 1);
+                const unsigned sh = 3u * (w.k + 1);
+                grow_to = (size_t)(sh < 64 ? round_max >> sh : 0) + (size_t)4 * (h->n + HBF_HALO) + 64;
+            }
+            int rc = ensure_cap(h, nx, need, grow_to);
             if (rc)
                 return rc;
         }
@@ -934,7 +980,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             old_total[ci].push_back(s.total);
     for (auto &w : works) {
         StageState &s = h->ch[w.c].st[w.k];
-        s.count = count_after(s.count, cur_stage_avg(h, w.k), w.j_new - w.j_old);
+        s.count64 = count_after64(s.count64, cur_stage_avg(h, w.k), w.j_new - w.j_old);
+        s.count = count_report(s.count64);
         s.segs = w.j_new;
         s.dec = w.p_new;
     }
@@ -1088,13 +1135,22 @@ int flush_all(psdc_handle *h)
     return drain(h);
 }
 
+// the stream is idle: nothing can still read the buffers that growth replaced
+int release_retired(psdc_handle *h)
+{
+    for (float *p : h->retired)
+        HIPCHK(h, hipFree(p));
+    h->retired.clear();
+    return PSDC_OK;
+}
+
 int flush_sync(psdc_handle *h)
 {
     int rc = flush_all(h);
     if (rc)
         return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PSDC_OK;
+    return release_retired(h);
 }
 
 // device -> caller memory through the handle's pinned buffer (pageable D2H copies take a slow,
@@ -1120,7 +1176,6 @@ int check_channel(psdc_handle *h, uint32_t channel)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
     if (channel >= h->n_channels)
         return fail(h, PSDC_ERR_ARG, "channel out of range");
-    HIPCHK(h, hipSetDevice(h->device));
     return PSDC_OK;
 }
 
@@ -1128,9 +1183,9 @@ int stitch_impl(uint32_t n, float nenbw, float power, uint32_t overlap, uint32_t
                 const uint32_t *counts, const uint32_t *avgs, const uint64_t *pendings,
                 const float *spectra, int keep_overlap, uint32_t min_count, int keep_transition_band,
                 float *psd_out, size_t psd_cap, size_t *psd_len, psdc_break *breaks,
-                size_t breaks_cap, size_t *n_breaks)
+                size_t breaks_cap, size_t *n_breaks, const uint64_t *counts64 = nullptr)
 {
-    // PsdCascade::psd (src/psd.rs:479-543)
+    // PsdCascade::psd (src/psd.rs:479-543); counts64: the counts in 64 bits for gain() where the u32 saturated
     const size_t bins = n / 2 + 1;
     size_t plen = 0, nb = 0;
     uint64_t decimation = 1ull << (3 * n_stages); // :482
@@ -1162,7 +1217,7 @@ int stitch_impl(uint32_t n, float nenbw, float power, uint32_t overlap, uint32_t
         }
         ++nb;
         if (include) { // :515-517
-            const float gsc = 1.0f / (stage_gain(n, counts[si], nenbw, power) * (float)decimation);
+            const float gsc = 1.0f / (stage_gain(n, counts64 ? counts64[si] : counts[si], nenbw, power) * (float)decimation);
             for (size_t k = start; k < end; ++k) {
                 if (psd_out) {
                     if (plen < psd_cap)
@@ -1281,7 +1336,8 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
         psdc_destroy(h);
         return nullptr;
     };
-    if ((e = hipSetDevice(device)) != hipSuccess)
+    DevScope dev_scope_(device);
+    if ((e = dev_scope_.err) != hipSuccess)
         return dev_fail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -1333,7 +1389,7 @@ void psdc_destroy(psdc_handle *h)
 {
     if (!h)
         return;
-    (void)hipSetDevice(h->device);
+    DevScope dev_scope_(h->device);
     if (h->copy_stream)
         (void)hipStreamSynchronize(h->copy_stream);
     if (h->stream)
@@ -1344,6 +1400,7 @@ void psdc_destroy(psdc_handle *h)
             (void)free_stage(h, s);
         (void)free_staging(h, c);
     }
+    (void)release_retired(h);
     if (h->d_partial)
         (void)hipFree(h->d_partial);
     if (h->d_spectra)
@@ -1385,10 +1442,15 @@ int psdc_reset(psdc_handle *h)
 {
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->upload_pending = false;
+    {
+        int rc = release_retired(h);
+        if (rc)
+            return rc;
+    }
     h->pend_red.clear(); // the state they would update is discarded
     h->pend_tail.clear();
     h->idle = true;
@@ -1410,7 +1472,7 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
 {
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     switch (option) {
     case PSDC_OPT_QUANTUM: {
         if (value < 1 || value > ((int64_t)1 << 30))
@@ -1453,7 +1515,7 @@ int psdc_set_detrend(psdc_handle *h, int kind)
         return fail(h, PSDC_ERR_UNIMPLEMENTED, "Detrend::Linear is unimplemented (src/psd.rs:110)");
     if (kind < 0 || kind > PSDC_DETREND_LINEAR)
         return fail(h, PSDC_ERR_ARG, "unknown detrend kind");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     int rc = flush_all(h); // segments completed so far keep the old setting
     if (rc)
         return rc;
@@ -1465,7 +1527,7 @@ int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count)
 {
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     int rc = flush_all(h);
     if (rc)
         return rc;
@@ -1479,6 +1541,7 @@ int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (len == 0)
         return PSDC_OK; // x.chunks() yields nothing: no stage is created (src/psd.rs:459)
     if (!x)
@@ -1525,13 +1588,23 @@ int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
 
 int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size_t len)
 {
+    return psdc_process_device_after(h, channel, d_x, len, nullptr);
+}
+
+int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x, size_t len, void *producer_event)
+{
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (len == 0)
         return PSDC_OK;
     if (!d_x)
         return fail(h, PSDC_ERR_ARG, "null input");
+    // everything enqueued on the handle's stream from here on runs behind the producer's event; the span is
+    // read only by work enqueued later (this call's round or a later, coalesced one)
+    if (producer_event)
+        HIPCHK(h, hipStreamWaitEvent(h->stream, static_cast<hipEvent_t>(producer_event), 0));
     Channel &c = h->ch[channel];
     const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
@@ -1568,6 +1641,9 @@ int psdc_process_device(psdc_handle *h, uint32_t channel, const float *d_x, size
     } else {
         c.spans.push_back({d_x, s0.total, len});
         s0.total += len;
+        c.span_max = std::max(c.span_max, len);
+        if (c.spans.size() > 1)
+            c.coalesced_seen = true;
     }
     if (h->n_channels == 1) {
         if (c.has_span() && !c.submitted && c.spans.size() < h->coalesce && !device_idle(h))
@@ -1585,6 +1661,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
     int rc = check_channel(h, 0);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (h->n_channels < 4)
         return fail(h, PSDC_ERR_ARG, "AdcDac frames carry four traces: need n_channels >= 4");
     if (n_frames == 0)
@@ -1730,6 +1807,27 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
     return PSDC_OK;
 }
 
+int psdc_record_consumed(psdc_handle *h, void *consumed_event)
+{
+    if (!h || !consumed_event)
+        return fail(h, PSDC_ERR_ARG, "null argument");
+    ON_DEVICE(h, h->device);
+    bool pend = false;
+    for (auto &c : h->ch)
+        pend = pend || c.has_span() || c.submitted;
+    if (pend) { // spans held back for coalescing go out now
+        int rc = advance(h);
+        if (rc)
+            return rc;
+    }
+    // the tail carry of a round (deferred into the next launch) still reads the end of the caller's span
+    int rc = launch_deferred(h, {});
+    if (rc)
+        return rc;
+    HIPCHK(h, hipEventRecord(static_cast<hipEvent_t>(consumed_event), h->stream));
+    return PSDC_OK;
+}
+
 int psdc_loss_read(psdc_handle *h, psdc_loss *out, int reset)
 {
     if (!h || !out)
@@ -1744,7 +1842,7 @@ int psdc_flush(psdc_handle *h)
 {
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     return flush_all(h);
 }
 
@@ -1752,7 +1850,7 @@ int psdc_sync(psdc_handle *h)
 {
     if (!h)
         return fail(nullptr, PSDC_ERR_ARG, "null handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     return flush_sync(h);
 }
 
@@ -1761,6 +1859,7 @@ int psdc_num_stages(psdc_handle *h, uint32_t channel)
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     rc = flush_all(h);
     if (rc)
         return rc;
@@ -1772,6 +1871,7 @@ int psdc_stage_info(psdc_handle *h, uint32_t channel, uint32_t stage, psdc_stage
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (!out)
         return fail(h, PSDC_ERR_ARG, "null output");
     rc = flush_all(h);
@@ -1794,6 +1894,7 @@ int psdc_stage_spectrum(psdc_handle *h, uint32_t channel, uint32_t stage, float 
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (!out)
         return fail(h, PSDC_ERR_ARG, "null output");
     rc = flush_sync(h);
@@ -1810,6 +1911,7 @@ int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     if (!out)
         return fail(h, PSDC_ERR_ARG, "null output");
     rc = flush_all(h);
@@ -1818,7 +1920,7 @@ int psdc_stage_gain(psdc_handle *h, uint32_t channel, uint32_t stage, float *out
     Channel &c = h->ch[channel];
     if (stage >= c.st.size())
         return fail(h, PSDC_ERR_ARG, "stage out of range");
-    *out = stage_gain(h->n, c.st[stage].count, h->nenbw, h->power);
+    *out = stage_gain(h->n, c.st[stage].count64, h->nenbw, h->power);
     return PSDC_OK;
 }
 
@@ -1827,6 +1929,7 @@ int psdc_stage_buf(psdc_handle *h, uint32_t channel, uint32_t stage, float *out,
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     rc = flush_sync(h);
     if (rc)
         return rc;
@@ -1856,6 +1959,7 @@ int psdc_read_channel(psdc_handle *h, uint32_t channel, uint32_t cap, uint32_t *
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     rc = spectra ? flush_sync(h) : flush_all(h);
     if (rc)
         return rc;
@@ -1891,6 +1995,7 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
+    ON_DEVICE(h, h->device);
     rc = flush_sync(h);
     if (rc)
         return rc;
@@ -1898,10 +2003,11 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
     const size_t ns = c.st.size();
     const size_t bins = h->n / 2 + 1;
     std::vector<uint32_t> counts(ns), avgs(ns);
-    std::vector<uint64_t> pend(ns);
+    std::vector<uint64_t> pend(ns), counts64(ns);
     std::vector<float> spectra(psd_out ? ns * bins : 0);
     for (size_t i = 0; i < ns; ++i) {
         counts[i] = c.st[i].count;
+        counts64[i] = c.st[i].count64;
         avgs[i] = cur_stage_avg(h, i);
         pend[i] = pending_for(h->geo, c.st[i].total);
     }
@@ -1913,7 +2019,7 @@ int psdc_psd(psdc_handle *h, uint32_t channel, int keep_overlap, uint32_t min_co
     }
     rc = stitch_impl(h->n, h->nenbw, h->power, h->geo.overlap, (uint32_t)ns, counts.data(), avgs.data(),
                      pend.data(), spectra.data(), keep_overlap, min_count, keep_transition_band, psd_out,
-                     psd_cap, psd_len, breaks, breaks_cap, n_breaks);
+                     psd_cap, psd_len, breaks, breaks_cap, n_breaks, counts64.data());
     if (rc)
         return fail(h, rc, "psdc_psd: output too small");
     return PSDC_OK;
@@ -1931,7 +2037,8 @@ psdc_handle *psdc_clone(psdc_handle *h)
         fail(nullptr, PSDC_ERR_ARG, "null handle");
         return nullptr;
     }
-    if (hipSetDevice(h->device) != hipSuccess || flush_sync(h) != PSDC_OK)
+    DevScope dev_scope_(h->device);
+    if (dev_scope_.err != hipSuccess || flush_sync(h) != PSDC_OK)
         return nullptr;
     psdc_handle *o = psdc_create(h->n, h->window_kind, h->n_channels, h->device);
     if (!o)
@@ -1941,6 +2048,9 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->avg_count = h->avg_count;
     o->quantum = h->quantum;
     o->profile = h->profile;
+    o->coalesce = h->coalesce;
+    o->coalesce_always = h->coalesce_always;
+    o->stage_limit = h->stage_limit;
     auto bad = [&](const char *what) -> psdc_handle * {
         fail(nullptr, PSDC_ERR_DEVICE, std::string("psdc_clone: ") + what);
         psdc_destroy(o);
@@ -1955,6 +2065,8 @@ psdc_handle *psdc_clone(psdc_handle *h)
             d.segs = s.segs;
             d.dec = s.dec;
             d.count = s.count;
+            d.count64 = s.count64;
+            d.sink_pos = s.sink_pos;
             d.buf.base = s.buf.base;
             d.buf.end = s.buf.base; // nothing resident yet
             if (ensure_room(o, d, s.total) != PSDC_OK)
@@ -2078,6 +2190,46 @@ float psdc_var_eval(int x_exp, int sinx_exp, float clip, size_t dc_cut, const fl
     return accu;
 }
 
+int psdc_trace_plot(const float *psd, const float *frequencies, size_t n, float fs, int integrate,
+                    float integral_start, float integral_end, float *rms, double *plot_xy, size_t plot_cap,
+                    size_t *n_points)
+{
+    // Trace::plot (src/bin/psd.rs:125-157) with Trapezoidal (src/bin/psd.rs:98-116), all in f32
+    if (n && (!psd || !frequencies))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_trace_plot: null input");
+    const float logfs = log10f(fs);                 // :127
+    float tx = 0.0f, ty = 0.0f, ti = 0.0f;          // Trapezoidal::default()
+    float pi = 0.0f;                                // :129
+    size_t np = 0;
+    bool overflow = false;
+    for (size_t k = 0; k < n; ++k) {
+        const float p = psd[k], f = frequencies[k];
+        const float di = (p + ty) * 0.5f * (f - tx); // Trapezoidal::push :105-110
+        tx = f;
+        ty = p;
+        ti += di;
+        const float hz = fs * f;
+        if (hz >= integral_start && hz <= integral_end) // RangeInclusive::contains :137
+            pi += di;
+        if (std::fpclassify(f) == FP_NORMAL) { // f32::is_normal :141
+            if (plot_xy) {
+                if (np < plot_cap) {
+                    plot_xy[2 * np] = (double)(log10f(f) + logfs);
+                    plot_xy[2 * np + 1] = (double)(integrate ? sqrtf(ti) : 10.0f * (log10f(p) - logfs));
+                } else {
+                    overflow = true;
+                }
+            }
+            ++np;
+        }
+    }
+    if (rms)
+        *rms = sqrtf(pi); // :156
+    if (n_points)
+        *n_points = np;
+    return overflow ? fail(nullptr, PSDC_ERR_CAPACITY, "psdc_trace_plot: plot output too small") : PSDC_OK;
+}
+
 int psdc_hbf_dec8(int device, const float *x, size_t len, float *y)
 {
     const size_t nout = len / 8;
@@ -2086,7 +2238,7 @@ int psdc_hbf_dec8(int device, const float *x, size_t len, float *y)
     if (!x || !y)
         return fail(nullptr, PSDC_ERR_ARG, "null argument");
     psdc_handle *h = nullptr;
-    HIPCHK(h, hipSetDevice(device));
+    ON_DEVICE(h, device);
     float *dx = nullptr, *dy = nullptr;
     HIPCHK(h, hipMalloc(&dx, sizeof(float) * nout * 8));
     HIPCHK(h, hipMalloc(&dy, sizeof(float) * nout));
@@ -2118,17 +2270,197 @@ int psdc_hbf_dec8(int device, const float *x, size_t len, float *y)
 int psdc_fill_noise_device(int device, float *d_x, size_t len, uint64_t seed, uint64_t first_index)
 {
     psdc_handle *h = nullptr;
-    HIPCHK(h, hipSetDevice(device));
+    ON_DEVICE(h, device);
     HIPCHK(h, launch_fill_noise(d_x, len, seed, first_index, nullptr));
     HIPCHK(h, hipStreamSynchronize(nullptr));
     return PSDC_OK;
+}
+
+// ---- Psd<N>: one stage (src/psd.rs:122-288) --------------------------------------------------
+// A one-channel handle whose stage 0 is the Psd and whose stage 1 is a SINK: the decimated stream that
+// PsdStage::process returns in `y` (src/psd.rs:246-268) lands in its stream buffer and is handed to the
+// caller instead of being analysed.  Same kernels, same bookkeeping as the cascade.
+} // extern "C"
+
+struct psdc_stage {
+    psdc_handle *h = nullptr;
+};
+
+extern "C" {
+
+psdc_stage *psdc_stage_create(uint32_t n, int window_kind, int device)
+{
+    psdc_handle *h = psdc_create(n, window_kind, 1, device);
+    if (!h)
+        return nullptr;
+    h->stage_limit = 1;
+    psdc_stage *st = new (std::nothrow) psdc_stage();
+    if (!st) {
+        psdc_destroy(h);
+        fail(nullptr, PSDC_ERR_NOMEM, "psdc_stage_create: out of memory");
+        return nullptr;
+    }
+    st->h = h;
+    return st;
+}
+
+void psdc_stage_destroy(psdc_stage *st)
+{
+    if (!st)
+        return;
+    psdc_destroy(st->h);
+    delete st;
+}
+
+psdc_stage *psdc_stage_clone(psdc_stage *st)
+{
+    if (!st) {
+        fail(nullptr, PSDC_ERR_ARG, "null stage");
+        return nullptr;
+    }
+    psdc_handle *o = psdc_clone(st->h);
+    if (!o)
+        return nullptr;
+    psdc_stage *c = new (std::nothrow) psdc_stage();
+    if (!c) {
+        psdc_destroy(o);
+        return nullptr;
+    }
+    c->h = o;
+    return c;
+}
+
+const char *psdc_stage_last_error(const psdc_stage *st) { return psdc_last_error(st ? st->h : nullptr); }
+
+int psdc_stage_set_avg(psdc_stage *st, uint32_t avg)
+{
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    return psdc_set_avg(st->h, avg, avg); // stage 0 uses min(count >> 0, limit) = avg (src/psd.rs:154-156)
+}
+
+int psdc_stage_set_detrend(psdc_stage *st, int detrend_kind)
+{
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    return psdc_set_detrend(st->h, detrend_kind);
+}
+
+int psdc_stage_process(psdc_stage *st, const float *x, size_t len, float *y, size_t cap, size_t *n_out)
+{
+    if (n_out)
+        *n_out = 0;
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    psdc_handle *h = st->h;
+    ON_DEVICE(h, h->device);
+    int rc = psdc_process(h, 0, x, len);
+    if (rc)
+        return rc;
+    rc = flush_sync(h); // every segment these samples complete is issued and decimated now (src/psd.rs:199-267)
+    if (rc)
+        return rc;
+    Channel &c = h->ch[0];
+    if (c.st.size() < 2)
+        return PSDC_OK; // nothing emitted yet (still inside the first segment or the drain)
+    StageState &sk = c.st[1];
+    const uint64_t avail = sk.total - sk.sink_pos;
+    if (avail == 0)
+        return PSDC_OK;
+    if (!y || cap < avail) // the reference indexes y[n..][..xb.len()] and panics (src/psd.rs:253)
+        return fail(h, PSDC_ERR_CAPACITY, "psdc_stage_process: y too small (needs x.len()/8 + n/8 items, src/psd.rs:187-190)");
+    rc = read_back(h, y, sk.buf.p[sk.buf.cur] + (sk.sink_pos - sk.buf.base), (size_t)avail);
+    if (rc)
+        return rc;
+    sk.sink_pos = sk.total; // handed over: the next round drops it from the stream buffer
+    if (n_out)
+        *n_out = (size_t)avail;
+    return PSDC_OK;
+}
+
+int psdc_stage_process_device(psdc_stage *st, const float *d_x, size_t len, float *d_y, size_t cap, size_t *n_out)
+{
+    if (n_out)
+        *n_out = 0;
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    psdc_handle *h = st->h;
+    ON_DEVICE(h, h->device);
+    int rc = psdc_process_device(h, 0, d_x, len);
+    if (rc)
+        return rc;
+    rc = flush_all(h);
+    if (rc)
+        return rc;
+    Channel &c = h->ch[0];
+    uint64_t avail = 0;
+    if (c.st.size() >= 2) {
+        StageState &sk = c.st[1];
+        avail = sk.total - sk.sink_pos;
+        if (avail) {
+            if (!d_y || cap < avail)
+                return fail(h, PSDC_ERR_CAPACITY, "psdc_stage_process_device: y too small");
+            HIPCHK(h, hipMemcpyAsync(d_y, sk.buf.p[sk.buf.cur] + (sk.sink_pos - sk.buf.base), sizeof(float) * avail,
+                                     hipMemcpyDeviceToDevice, h->stream));
+            sk.sink_pos = sk.total;
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // d_x has been read, d_y is complete
+    rc = release_retired(h);
+    if (rc)
+        return rc;
+    if (n_out)
+        *n_out = (size_t)avail;
+    return PSDC_OK;
+}
+
+int psdc_stage_get_spectrum(psdc_stage *st, float *out)
+{
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    if (!out)
+        return fail(st->h, PSDC_ERR_ARG, "null output");
+    if (st->h->ch[0].st.empty()) { // a fresh Psd: spectrum is all zeros (src/psd.rs:146)
+        memset(out, 0, sizeof(float) * (st->h->n / 2 + 1));
+        return PSDC_OK;
+    }
+    return psdc_stage_spectrum(st->h, 0, 0, out);
+}
+
+int psdc_stage_get_count(psdc_stage *st, uint32_t *count)
+{
+    if (!st || !count)
+        return fail(st ? st->h : nullptr, PSDC_ERR_ARG, "null argument");
+    *count = st->h->ch[0].st.empty() ? 0u : st->h->ch[0].st[0].count;
+    return PSDC_OK;
+}
+
+int psdc_stage_get_gain(psdc_stage *st, float *gain)
+{
+    if (!st || !gain)
+        return fail(st ? st->h : nullptr, PSDC_ERR_ARG, "null argument");
+    psdc_handle *h = st->h;
+    *gain = stage_gain(h->n, h->ch[0].st.empty() ? 0 : h->ch[0].st[0].count64, h->nenbw, h->power);
+    return PSDC_OK;
+}
+
+int psdc_stage_get_buf(psdc_stage *st, float *out, size_t cap, size_t *len)
+{
+    if (!st)
+        return fail(nullptr, PSDC_ERR_ARG, "null stage");
+    if (st->h->ch[0].st.empty()) {
+        if (len)
+            *len = 0;
+        return PSDC_OK;
+    }
+    return psdc_stage_buf(st->h, 0, 0, out, cap, len);
 }
 
 int psdc_profile_read(psdc_handle *h, psdc_profile *out, int reset)
 {
     if (!h || !out)
         return fail(h, PSDC_ERR_ARG, "null argument");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h, h->device);
     int rc = collect_profile(h);
     if (rc)
         return rc;

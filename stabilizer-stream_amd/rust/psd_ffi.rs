@@ -147,3 +147,123 @@ impl<const N: usize> Drop for PsdCascade<N> {
         unsafe { psdc_destroy(self.0.as_ptr()) }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Psd<N>: one stage with the reference's `PsdStage` trait (src/psd.rs:122-288), e.g. for the crate's
+// own test (src/psd.rs:615-632).  `pub use psd_gpu::Psd;` next to `PsdCascade` in src/lib.rs.
+// ---------------------------------------------------------------------------------------------
+
+pub use crate::psd::PsdStage; // the trait stays the reference's own (src/psd.rs:163-193)
+
+#[repr(C)]
+struct PsdcStage {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    fn psdc_stage_create(n: u32, window_kind: c_int, device: c_int) -> *mut PsdcStage;
+    fn psdc_stage_destroy(s: *mut PsdcStage);
+    fn psdc_stage_clone(s: *mut PsdcStage) -> *mut PsdcStage;
+    fn psdc_stage_set_avg(s: *mut PsdcStage, avg: u32) -> c_int;
+    fn psdc_stage_set_detrend(s: *mut PsdcStage, kind: c_int) -> c_int;
+    fn psdc_stage_process(s: *mut PsdcStage, x: *const f32, len: usize, y: *mut f32, cap: usize, n_out: *mut usize) -> c_int;
+    fn psdc_stage_get_spectrum(s: *mut PsdcStage, out: *mut f32) -> c_int;
+    fn psdc_stage_get_count(s: *mut PsdcStage, count: *mut u32) -> c_int;
+    fn psdc_stage_get_gain(s: *mut PsdcStage, gain: *mut f32) -> c_int;
+    fn psdc_stage_get_buf(s: *mut PsdcStage, out: *mut f32, cap: usize, len: *mut usize) -> c_int;
+    fn psdc_stage_last_error(s: *const PsdcStage) -> *const c_char;
+}
+
+/// Power spectral density accumulator and decimator on one MI355X (drop-in for `psd::Psd<N>`).
+///
+/// `spectrum()` and `buf()` return slices in the reference; the accumulators live in HBM here, so the
+/// shim keeps host copies that are refreshed by `process()` (the only call that changes them).
+pub struct Psd<const N: usize> {
+    s: NonNull<PsdcStage>,
+    spectrum: Vec<f32>, // N/2 + 1
+    buf: Vec<f32>,      // pending input items
+}
+
+unsafe impl<const N: usize> Send for Psd<N> {}
+
+impl<const N: usize> Psd<N> {
+    fn check(&self, rc: c_int) {
+        if rc < 0 {
+            let msg = unsafe { CStr::from_ptr(psdc_stage_last_error(self.s.as_ptr())) };
+            panic!("psdcascade: {}", msg.to_string_lossy());
+        }
+    }
+
+    /// `Psd::new(fft, win)` (src/psd.rs:137): the FFT plan is the library's own; `hann` selects
+    /// `Window::hann()` / `Window::rectangular()`.
+    pub fn new(hann: bool) -> Self {
+        let s = unsafe { psdc_stage_create(N as u32, hann as c_int, 0) };
+        let s = NonNull::new(s).unwrap_or_else(|| {
+            let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
+            panic!("psdcascade: {}", msg.to_string_lossy())
+        });
+        Self { s, spectrum: vec![0.0; N / 2 + 1], buf: Vec::new() }
+    }
+
+    pub fn set_avg(&mut self, avg: u32) {
+        self.check(unsafe { psdc_stage_set_avg(self.s.as_ptr(), avg) });
+    }
+
+    pub fn set_detrend(&mut self, d: Detrend) {
+        self.check(unsafe { psdc_stage_set_detrend(self.s.as_ptr(), d as c_int) });
+    }
+
+    fn refresh(&mut self) {
+        let s = self.s.as_ptr();
+        self.check(unsafe { psdc_stage_get_spectrum(s, self.spectrum.as_mut_ptr()) });
+        let mut len = 0usize;
+        self.check(unsafe { psdc_stage_get_buf(s, std::ptr::null_mut(), 0, &mut len) });
+        self.buf.resize(len, 0.0);
+        if len > 0 {
+            self.check(unsafe { psdc_stage_get_buf(s, self.buf.as_mut_ptr(), len, &mut len) });
+        }
+    }
+}
+
+impl<const N: usize> PsdStage for Psd<N> {
+    fn process<'a>(&mut self, x: &[f32], y: &'a mut [f32]) -> &'a mut [f32] {
+        let mut n = 0usize;
+        // too small a `y` returns PSDC_ERR_CAPACITY -> panic, like the slice index at src/psd.rs:253
+        self.check(unsafe { psdc_stage_process(self.s.as_ptr(), x.as_ptr(), x.len(), y.as_mut_ptr(), y.len(), &mut n) });
+        self.refresh();
+        &mut y[..n]
+    }
+
+    fn spectrum(&self) -> &[f32] {
+        &self.spectrum
+    }
+
+    fn gain(&self) -> f32 {
+        let mut g = 0f32;
+        self.check(unsafe { psdc_stage_get_gain(self.s.as_ptr(), &mut g) });
+        g
+    }
+
+    fn count(&self) -> u32 {
+        let mut c = 0u32;
+        self.check(unsafe { psdc_stage_get_count(self.s.as_ptr(), &mut c) });
+        c
+    }
+
+    fn buf(&self) -> &[f32] {
+        &self.buf
+    }
+}
+
+impl<const N: usize> Clone for Psd<N> {
+    fn clone(&self) -> Self {
+        let s = unsafe { psdc_stage_clone(self.s.as_ptr()) };
+        Self { s: NonNull::new(s).expect("psdc_stage_clone failed"), spectrum: self.spectrum.clone(), buf: self.buf.clone() }
+    }
+}
+
+impl<const N: usize> Drop for Psd<N> {
+    fn drop(&mut self) {
+        unsafe { psdc_stage_destroy(self.s.as_ptr()) }
+    }
+}

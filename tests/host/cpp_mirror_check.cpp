@@ -50,6 +50,43 @@ int main()
         std::printf("stage fft %zu x%zu: count %u, bins %zu..%zu, rbw %.3g\n", br.fft_size, br.decimation, br.count,
                     br.bins.first, br.bins.second, br.rbw());
     }
+    // the tail of stream_test (src/bin/stream_test.rs:61-71): FDEV sweep over tau = 1, 2, 4, ... on the merged PSD
+    {
+        const Var var{.x_exp = -2, .sinx_exp = 4, .clip = 1.0f, .dc_cut = 1}; // VarBuilder::default().dc_cut(1).clip(1.0)
+        int n_tau = 0;
+        for (float tau = 1.0f; tau <= (float)(b.front().effective_fft_size() / 2); tau *= 2.0f) {
+            const float v = var.eval(y, f, tau);
+            if (!(v >= 0.0f) || !std::isfinite(std::sqrt(v)))
+                ++bad;
+            // white frequency-noise level: S_phi = 2 flat => the main-lobe variance falls with tau; just sanity here,
+            // the bit-exact comparison with the restatement is tests/test_oracle_reference.py
+            if (n_tau < 3)
+                std::printf("fdev(tau=%g) = %.6g\n", tau, std::sqrt(v));
+            ++n_tau;
+        }
+        std::printf("fdev sweep: %d taus\n", n_tau);
+        const auto [rms, pts] = trace_plot(y, f, 1.0f, true, 0.0f, 1.0f); // Trace::plot, whole band
+        if (std::fabs(rms - 1.0f) > 0.05f || pts.size() + 1 != f.size())
+            ++bad;
+        std::printf("integrated rms %.4f over %zu plot points\n", rms, pts.size());
+    }
+    // the reference's own single-stage test (src/psd.rs:615-632) through the Psd<N> mirror
+    {
+        std::vector<float> xs(total), ys(total >> 3);
+        for (auto &v : xs)
+            v = (u(rng) - 0.5f) * std::sqrt(12.0f);
+        Psd<N> s; // Psd::<N>::new(plan_fft_forward(N), Arc::new(Window::hann()))
+        const auto out = s.process(xs, ys);
+        if (out.size() != (xs.size() >> 3) - (size_t)psdc_hbf_response_length(3)) { // :622
+            std::fprintf(stderr, "Psd::process returned %zu items\n", out.size());
+            ++bad;
+        }
+        const float g = 1.0f / s.gain();
+        for (const float p : s.spectrum())
+            if (std::fabs(p * g * 0.5 - 1.0) > 10.0 / std::sqrt((double)s.count())) // :623-632
+                ++bad;
+        std::printf("Psd<%zu>: %zu outputs, count %u, %zu pending\n", N, out.size(), s.count(), s.buf().size());
+    }
     bool threw = false;
     try {
         copy.set_detrend(Detrend::Linear); // unimplemented!() in the reference (src/psd.rs:110)

@@ -102,6 +102,38 @@ int main()
             bad = 1;
         }
     }
+    // past 2^32 segments: the reference's u32 count wraps there (src/psd.rs:225 `count += 1`);
+    // the library counts in 64 bits, reports a saturated u32 and keeps plain-sum averaging plain
+    {
+        const uint32_t MAXU = 0xFFFFFFFFu;
+        uint64_t c = 0;
+        for (int i = 0; i < 5; ++i) // five batches of 2^30 segments: crosses 2^32 in the fifth
+            c = count_after64(c, MAXU, 1ull << 30);
+        if (c != 5ull << 30 || count_report(c) != MAXU || count_report(c - (2ull << 30)) != (3u << 30)) {
+            printf("64-bit count past 2^32: %llu -> %u\n", (unsigned long long)c, count_report(c));
+            bad = 1;
+        }
+        if (count_after(MAXU - 3, MAXU, 10) != MAXU) { // saturates, does not wrap to 6
+            printf("count_after wrapped: %u\n", count_after(MAXU - 3, MAXU, 10));
+            bad = 1;
+        }
+        EwmaPlan p = plan_ewma(MAXU, MAXU, 1000); // saturated count, plain sum: every weight exactly 1
+        if (p.ewma || p.g_total != 1.0 || ewma_weight(p, 1) != 1.0 || ewma_weight(p, 500) != 1.0) {
+            printf("plain sum past saturation became an EWMA: ewma=%d g_total=%.17g\n", (int)p.ewma, p.g_total);
+            bad = 1;
+        }
+        // a finite limit keeps the reference rule: saturates at avg + 1, in 64 bits too
+        if (count_after64(7, 100, 1ull << 40) != 101 || count_after(101, 100, 5) != 101) {
+            printf("finite avg saturation broken\n");
+            bad = 1;
+        }
+        // avg >= 2^25: gamma = avg / (avg + 1) rounds to 1.0f -- plain sum, no EWMA kernel variant
+        EwmaPlan q = plan_ewma(1u << 26, 1u << 26, 64);
+        if (q.ewma || q.g_total != 1.0) {
+            printf("gamma == 1.0f treated as EWMA\n");
+            bad = 1;
+        }
+    }
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }

@@ -931,3 +931,145 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
             if rb.size:
                 assert np.max(np.abs(gb - rb)) <= 1e-5 * max(1e-3, float(np.max(np.abs(rb))))
     g.close()
+
+
+# ---- Psd<N>: the single stage (src/psd.rs:122-288) -------------------------------------------------------
+
+def test_single_stage_reference_test_shape(pkg, ora, gpu_required):
+    """The reference's own single-stage test (src/psd.rs:615-632) through psdc_stage_*: Psd::<512>::new(..,
+    Window::hann()), y = s.process(&x, &mut y) with y of x.len() >> 3 items, y.len() == (x.len() >> 3) - 35,
+    every bin of spectrum * 1/gain within 10/sqrt(count) of PSD = 2 -- and the decimated stream, the spectrum,
+    count, gain and buf() against ora.Psd(n).process on the same samples."""
+    n = 1 << 9
+    x = pkg.noise_host(1 << 16, seed=0x7654321)
+    s = pkg.Psd(n)
+    y = s.process(x, np.zeros(x.size >> 3, dtype=np.float32))
+    assert y.size == (x.size >> 3) - pkg.hbf_response_length(3)  # :622
+    p = s.spectrum() / s.gain()
+    assert np.all(np.abs(p * 0.5 - 1.0) < 10.0 / np.sqrt(s.count()))  # :623-632
+    ref = ora.Psd(n, "f64")
+    yr = ref.process(x)
+    assert y.shape == yr.shape
+    assert np.max(np.abs(y - yr)) <= 4e-6 * np.max(np.abs(yr))
+    assert s.count() == ref.count() and s.gain() == pytest.approx(ref.gain(), rel=1e-6)
+    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<512> spectrum", pure=True)
+    assert s.buf().size == ref.pending()
+    s.close()
+
+
+@pytest.mark.parametrize("n,window,detrend", [(64, "hann", "none"), (256, "hann", "mean"), (1024, "hann", "none"),
+                                              (1024, "hann", "span"), (4096, "hann", "midpoint"), (128, "rect", "none")])
+def test_single_stage_chunked(pkg, ora, gpu_required, n, window, detrend):
+    """PsdStage::process call by call with odd chunk sizes (empty, shorter than a segment, many segments): every
+    call returns exactly the items the reference's loop emits for the segments that call completes, and the
+    concatenation is the /8-decimated stream minus the one-time drain."""
+    rng = np.random.default_rng(n)
+    x = make_signal(pkg, 90 * n + 77, seed=400 + n, tone=0.3, dc=0.2)
+    s = pkg.Psd(n, pkg.Window.HANN if window == "hann" else pkg.Window.RECTANGULAR)
+    s.set_detrend(pkg.Detrend[detrend.upper()])
+    ref = ora.Psd(n, "f64", window=window, detrend=detrend)
+    ys, yrs, i = [], [], 0
+    sizes = [0, 5, n - 6, 1, 3 * n + 3, 17, 40 * n]
+    while i < x.size:
+        m = sizes.pop(0) if sizes else int(rng.integers(0, 9 * n))
+        c = x[i:i + m]
+        i += m
+        y, yr = s.process(c), ref.process(c)
+        assert y.size == yr.size, f"call of {c.size} samples: {y.size} vs {yr.size} items"
+        ys.append(y.copy())
+        yrs.append(yr)
+        assert s.count() == ref.count() and s.buf().size == ref.pending()
+    y, yr = np.concatenate(ys), np.concatenate(yrs)
+    assert np.max(np.abs(y - yr)) <= 4e-6 * np.max(np.abs(yr))
+    r32 = ora.Psd(n, "f32", window=window, detrend=detrend)
+    r32.process(x)
+    assert_psd_close(s.spectrum(), ref.spectrum(), f"Psd<{n}> {window} {detrend}", ref_f32=r32.spectrum())
+    # clone carries the whole state (#[derive(Clone)] src/psd.rs:122)
+    t = s.clone()
+    extra = pkg.noise_host(5 * n, seed=9)
+    ya, yb = s.process(extra), t.process(extra)
+    assert np.array_equal(ya, yb) and np.array_equal(s.spectrum(), t.spectrum())
+    # too small a y is the reference's slice-index panic (src/psd.rs:253)
+    with pytest.raises(pkg.PsdError) as e:
+        s.process(pkg.noise_host(16 * n, seed=10), np.zeros(3, dtype=np.float32))
+    assert e.value.code == pkg.ERR_CAPACITY
+    s.close()
+    t.close()
+
+
+def test_single_stage_finite_averaging_and_device_io(pkg, ora, gpu_required):
+    """Psd::set_avg (src/psd.rs:154-156) and the device-resident form of process."""
+    import torch
+    n = 1024
+    x = make_signal(pkg, (1 << 20) + 40, seed=77, tone=0.2)
+    s = pkg.Psd(n)
+    s.set_avg(25)
+    ref = ora.Psd(n, "f64", avg=25)
+    d = torch.from_numpy(x).cuda()
+    y = torch.zeros(x.size // 8 + n // 8, dtype=torch.float32, device="cuda")
+    m = s.process_device(d.data_ptr(), x.size, y.data_ptr(), y.numel())
+    yr = ref.process(x)
+    assert m == yr.size
+    assert np.max(np.abs(y[:m].cpu().numpy() - yr)) <= 4e-6 * np.max(np.abs(yr))
+    assert s.count() == ref.count() == 26
+    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<1024> avg 25")
+    s.close()
+
+
+def test_producer_on_another_stream(pkg, ora, gpu_required):
+    """psdc_process_device_after / psdc_record_consumed: the span is produced on a torch side stream and handed
+    over with an event instead of a host synchronisation; the buffer is rewritten as soon as the consumed
+    event allows.  The spectra must be those of the stream as it was produced."""
+    import torch
+    n, span, reps = 1024, 1 << 22, 6
+    side = torch.cuda.Stream()
+    g = pkg.PsdCascadeBank(n)
+    buf = torch.empty(span, dtype=torch.float32, device="cuda")
+    chunks = []
+    consumed = torch.cuda.Event()
+    for r in range(reps):
+        xh = pkg.noise_host(span, seed=600 + r)
+        chunks.append(xh)
+        src = torch.from_numpy(xh).pin_memory()
+        with torch.cuda.stream(side):
+            if r:
+                side.wait_event(consumed)  # the library has read the previous content for the last time
+            tmp = src.to("cuda", non_blocking=True)
+            for _ in range(20):  # keep the producer busy for a while: a missing wait would read stale data
+                tmp = tmp * 1.0
+            buf.copy_(tmp)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        g.process_device(0, buf.data_ptr(), span, after=ready.cuda_event)
+        consumed = torch.cuda.Event()
+        consumed.record()  # (creates the handle)
+        g.record_consumed(consumed.cuda_event)
+    check_against_oracle(pkg, ora, g, chunks, n, what="event-ordered producer", pure_min_count=4)
+    g.close()
+    torch.cuda.synchronize()
+
+
+def test_count_past_two_to_the_32(pkg, gpu_required):
+    """More than 2^32 segments in one stage (N = 256: 2^32 x 128 samples, about a second of ingest): the
+    reference's u32 count wraps there (src/psd.rs:225); the library reports a saturated count, keeps the
+    64-bit one for gain(), and unit white noise still reads PSD = 2."""
+    import torch
+    n, total = 256, 1 << 26
+    d = torch.empty(total, dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), total, seed=31337)
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 1)
+    reps = (2 ** 32 * (n // 2)) // total + 40
+    for _ in range(reps):
+        g.process_device(0, d.data_ptr(), total)
+    segs = 1 + (reps * total - n) // (n // 2)
+    assert segs > 2 ** 32
+    info = g.stage_info(0, 0)
+    assert info["count"] == 0xFFFFFFFF  # saturated, not wrapped
+    gain = g.stage_gain(0, 0)
+    assert gain == pytest.approx(float(segs) * (n // 2) * 0.375, rel=1e-6)
+    p = g.stage_spectrum(0, 0) / gain
+    assert np.all(np.abs(p[1:-1] * 0.5 - 1.0) < 10.0 / np.sqrt(total / (n // 2)))
+    psd, br = g.psd(0)
+    assert np.all(np.isfinite(psd)) and abs(float(np.mean(psd[br[-1].start + 1:-1])) * 0.5 - 1.0) < 1e-3
+    g.close()

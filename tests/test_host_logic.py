@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), f"libpsdcascade.so does not export {name}"
     assert sorted(pkg.EXPORTS) == declared
-    assert L.psdc_abi_version() == 1
+    assert L.psdc_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (psdc_[a-z0-9_]+)", out))
     assert exported == set(declared)

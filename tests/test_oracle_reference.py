@@ -211,3 +211,80 @@ def test_short_first_call_then_full_chunk(ora):
         assert a.stage_info(k) == b.stage_info(k)
         np.testing.assert_array_equal(a.stage_spectrum(k), b.stage_spectrum(k))
         np.testing.assert_array_equal(a.stage_buf(k), b.stage_buf(k))
+
+
+def test_config1_counts(pkg, ora):
+    """BASELINE config 1: 1 channel, N = 1024, 2^20 samples on the CPU path -- four stages
+    with spectra, counts 2047 / 254 / 30 / 2, and a fifth stage holding 157 pending samples with no segment yet
+    (excluded by min_count = 1).  The closed-form planner of the library must say the same."""
+    n, total = 1024, 1 << 20
+    x = pkg.noise_host(total, 0x7654321)
+    o = ora.PsdCascade(n, "f32")
+    for i in range(0, total, 1 << 16):  # process() calls of 65536 samples like src/psd.rs:554-559
+        o.process(x[i:i + (1 << 16)])
+    assert o.num_stages == 5
+    assert [o.stage_info(k)["count"] for k in range(5)] == [2047, 254, 30, 2, 0]
+    assert o.stage_info(4)["pending"] == 157
+    plan = pkg.plan_counts(n, total)
+    assert [(segs, pend) for _, segs, pend in plan] == [(o.stage_info(k)["count"], o.stage_info(k)["pending"]) for k in range(5)]
+    p, br, cbr = o.psd()
+    assert [b["include"] for b in br] == [0, 1, 1, 1, 1]  # lowest rate first: the fifth stage is not included
+    assert p.size == 409 + 357 * 2 + 461 == 1584          # merged length for K = 4 (SURVEY A9)
+    f = o.frequencies(cbr)
+    assert f[0] == 0.0 and f[-1] == 0.5 and np.all(np.diff(f) > 0)
+    for b in br:  # the reference's own bound (src/psd.rs:634-643)
+        if b["include"]:
+            seg = p[b["start"]:b["start"] + b["bins_end"] - b["bins_start"]]
+            assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(b["count"]))
+
+
+def test_trace_plot_matches_the_restatement(pkg, ora):
+    """Trace::plot / Trapezoidal (src/bin/psd.rs:98-157): the library's host function against the oracle's
+    restatement (same f32 operations: bit-equal), and the closed forms a flat PSD gives."""
+    n = 1024
+    x = pkg.noise_host(1 << 18, 7)
+    o = ora.PsdCascade(n, "f32")
+    o.process(x)
+    p, br, cbr = o.psd()
+    f = o.frequencies(cbr)
+    for fs, integ, lo, hi in [(1.0, False, 0.0, float("inf")), (1e6, True, 10.0, 1e5), (781250.0, True, 0.0, 100e3),
+                              (2.0, False, 0.3, 0.31)]:
+        r_lib, xy_lib = pkg.trace_plot(p, f, fs, integ, lo, hi)
+        r_ora, xy_ora = ora.trace_plot(p, f, fs, integ, lo, hi)
+        assert r_lib == r_ora and np.array_equal(xy_lib, xy_ora)
+        assert xy_lib.shape == (f.size - 1, 2)  # f = 0 is not a normal float: no plot point (:141)
+    # unit white noise: PSD = 2 over f in [0, 0.5] integrates to the variance 1
+    rms, xy = pkg.trace_plot(p, f, 1.0, True)
+    assert abs(rms - 1.0) < 0.02
+    assert abs(xy[-1, 1] - rms) < 1e-6 and xy[-1, 0] == pytest.approx(np.log10(0.5))
+    # flat PSD 3.0 on an irregular grid: the trapezoid from (0, 0) adds (3 + 0)/2 * f0 for the first interval
+    ff = np.array([0.01, 0.02, 0.05, 0.1, 0.5], dtype=np.float32)
+    rms, _ = pkg.trace_plot(np.full(5, 3.0, np.float32), ff, 1.0, False)
+    assert rms == pytest.approx(np.sqrt(1.5 * 0.01 + 3.0 * 0.49), rel=1e-6)
+    rms, _ = pkg.trace_plot(np.full(5, 3.0, np.float32), ff, 100.0, False, 2.0, 10.0)  # bins at 2, 5, 10 Hz
+    assert rms == pytest.approx(np.sqrt(3.0 * (0.1 - 0.01)), rel=1e-6)
+    assert pkg.trace_plot(np.zeros(0, np.float32), np.zeros(0, np.float32))[0] == 0.0
+
+
+def test_stream_test_tail_on_the_oracle(pkg, ora):
+    """The tail of src/bin/stream_test.rs (:57-71): psd(&MergeOpts::default()), then the FDEV sweep
+    Var{dc_cut: 1, clip: 1.0}.eval(psd, f, tau).sqrt() for tau = 1, 2, 4, ... <= effective_fft_size/2 --
+    the library's host helpers on the oracle's merged PSD must reproduce the restatement bit for bit."""
+    n = 512  # the FFT size both reference binaries hard-code
+    o = ora.PsdCascade(n, "f32")
+    o.set_detrend("midpoint")  # stream_test.rs:41
+    o.process(pkg.noise_host(1 << 18, 11))
+    y, br, cbr = o.psd()
+    f = o.frequencies(cbr)
+    assert np.array_equal(f, pkg.Break.frequencies([pkg.Break(b["start"], bool(b["include"]), b["count"], b["avg"],
+                                                               range(b["bins_start"], b["bins_end"]), b["fft_size"],
+                                                               b["decimation"], b["pending"], b["processed"]) for b in br]))
+    eff = br[0]["fft_size"] * br[0]["decimation"]
+    tau, n_tau = 1.0, 0
+    while tau <= eff // 2:
+        a = pkg.var_eval(y, f, tau, dc_cut=1, clip=1.0)
+        b = ora.var_eval(y, f, tau, dc_cut=1, clip=1.0)
+        assert a == b and a >= 0.0
+        tau *= 2.0
+        n_tau += 1
+    assert n_tau == int(np.log2(eff // 2)) + 1
