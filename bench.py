@@ -3,12 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of PsdCascade<1024> over one batch of 2^26 synthetic raw-f32
-samples already resident in HBM (BASELINE.json configs[1]: 1-channel raw f32,
-N=1024, >= 6 stages).  With N > 1 GPUs (one process per GPU under
-torch.distributed.run) every rank runs the same workload on its own channel
-(weak scaling, channels shard with no data-path collective) and the final
-per-stage spectra are gathered to rank 0 over RCCL inside the timed region.
+N = 1 (default): BASELINE.json configs[1] -- 1-channel raw f32, PsdCascade N=1024, >= 6 stages.  A step =
+`--passes` (16) consecutive passes of the cascade over one 2^26-sample batch of synthetic raw-f32 samples
+already resident in HBM, i.e. 2^30 stream samples per step (the stream simply continues from pass to pass).
+N > 1: BASELINE.json configs[3] -- raw f32 channels sharded 8 per GPU (64 channels at N = 8), N=1024,
+2^24 samples per channel per pass, `--passes` (8) passes per step; one process per GPU, no data-path
+collective, and the final per-stage spectra of all channels gathered to rank 0 over RCCL inside the
+timed region (weak scaling: the per-GPU work is fixed).
+Started without a launcher (`WORLD_SIZE` unset) and with --gpus N > 1 the script starts the N ranks itself
+(`python -m torch.distributed.run`), from a parent that never touches the GPU, and relays rank 0's line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -44,7 +47,16 @@ def cpu_baseline(n, seconds=12.0):
             c.process(x)
         done += 16 * x.size
     dt = time.perf_counter() - t0
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": done / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "host": f"{model}, {os.cpu_count()} logical cores visible",
             "sample": f"{done} samples ({done // x.size} process() calls of 65536) in {dt:.1f} s, "
                       f"C restatement of src/psd.rs (oracle/, f32, gcc -O3 -march=native), not the Rust crate; "
                       f"reference quotes >200 MS/s/core for N=512 (README.md:11)"}
@@ -70,9 +82,10 @@ def host_fed_rate(pkg, n, device, seconds=2.0):
                     "hipMemcpyAsync, kernels); link-bound"}
 
 
-def measured_traffic(kernel):
-    """HBM bytes per dominant launch from the latest committed PMC passes (profiles/*_traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE of the same bench command under rocprofv3 --pmc); None if not measured."""
+def measured_traffic(kernel, n, channels, samples):
+    """HBM bytes per one-span dominant launch from the latest committed PMC passes for this workload shape
+    (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of `bench.py --coalesce 1 --passes 1` under
+    rocprofv3 --pmc); None if this shape was not measured."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
@@ -80,45 +93,95 @@ def measured_traffic(kernel):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel") == kernel:
-            best = d
+        if d.get("kernel") != kernel:
+            continue
+        if (d.get("fft_size") or 1024) != n or (d.get("channels") or 1) != channels:
+            continue
+        if (d.get("samples_per_launch") or (1 << 26)) != samples * channels:
+            continue
+        best = d
     return best
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks (one per GPU) under torch.distributed.run from this
+    process, which has not initialised the GPU (no torch.cuda / HIP call so far), relay their output and
+    exit with the launcher's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--passes", type=int, default=None,
+                    help="passes of the cascade over the resident batch per step (default: 16 at 1 channel x 2^26, "
+                         "8 at 8 channels x 2^24: 2^30 stream samples per GPU per step); the stream continues across passes")
     ap.add_argument("--clock-warm-ms", type=float, default=300.0,
                     help="untimed run of the same kernels on a scratch cascade before the warm-up steps, so that short "
-                         "timed regions do not measure the GPU's clock ramp (0.1 ms steps: 100 of them are 13 ms)")
+                         "timed regions do not measure the GPU's clock ramp")
     ap.add_argument("--n", type=int, default=1024, help="FFT size N")
-    ap.add_argument("--log2-batch", type=int, default=26, help="samples per channel per step = 2^this")
-    ap.add_argument("--channels-per-gpu", type=int, default=1)
+    ap.add_argument("--log2-batch", type=int, default=None,
+                    help="samples per channel per pass = 2^this (default 26 at --gpus 1, 24 at --gpus > 1)")
+    ap.add_argument("--channels-per-gpu", type=int, default=None, help="default 1 at --gpus 1, 8 at --gpus > 1 (config 4)")
     ap.add_argument("--detrend", default="none")
     ap.add_argument("--coalesce", type=int, default=None,
-                    help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 4)")
+                    help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 8)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launch command instead of running it")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and (args.gpus > 1 or args.dry_run_launch):
+        # no launcher around us: be the launcher (nothing has touched the GPU in this process)
+        argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
+        raise SystemExit(launch_ranks(args, argv))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number as {args.gpus} GPUs")
+    multi = args.gpus > 1
+    if args.channels_per_gpu is None:
+        args.channels_per_gpu = 8 if multi else 1
+    if args.log2_batch is None:
+        args.log2_batch = 24 if multi else 26
+    if args.passes is None:  # 2^30 stream samples per GPU per step
+        args.passes = max(1, (1 << 30) // (args.channels_per_gpu << args.log2_batch))
 
     import torch
     torch.set_num_threads(1)  # no CPU tensor math here; keep torch's thread pool out of the timed loop
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the PSD path has no CPU fallback)")
     if args.single_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPUs visible "
+                         f"(use --single-device --backend gloo to rehearse on one GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("PSD_BENCH_FORCE_DIST"):  # (forced: a 1-rank group, to run the RCCL calls on one GPU)
@@ -150,9 +213,12 @@ def main():
         bufs.append(d)
     torch.cuda.synchronize()
 
+    P = args.passes
+
     def step():
-        for c in range(C):
-            bank.process_device(c, bufs[c].data_ptr(), T)
+        for _ in range(P):
+            for c in range(C):
+                bank.process_device(c, bufs[c].data_ptr(), T)
 
     def barrier():
         if dist is not None:
@@ -231,7 +297,7 @@ def main():
     if prof_scratch is not None:
         prof_all = {k: prof_all[k] + prof_scratch[k] for k in prof_all}
     if rank == 0:
-        total_samples = float(args.steps) * T * C * world
+        total_samples = float(args.steps) * P * T * C * world
         msps = total_samples / dt / 1e6
         psd, breaks = merged[0]
         assert len(merged) == C * world
@@ -240,17 +306,20 @@ def main():
         ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
         kname = "fused_kernel" if n in (256, 512, 1024) else ("bigfused_kernel" if n <= 16384 and n >= 2048 else "welch_kernel")
-        tr = measured_traffic(kname) if (C == 1 and args.log2_batch == 26) else None
+        tr = measured_traffic(kname, n, C, T)
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,
             "value": msps, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{C * world}-channel raw f32 stream ({C} per GPU), PsdCascade N={n}, Hann, "
-                                   f"detrend {args.detrend}, 2^{args.log2_batch} samples/channel/step resident in HBM, "
+            "config": {"workload": f"{'BASELINE configs[3]' if multi else 'BASELINE configs[1]'}: {C * world}-channel raw f32 stream "
+                                   f"({C} per GPU), PsdCascade N={n}, Hann, detrend {args.detrend}, a step = {P} passes over "
+                                   f"2^{args.log2_batch} samples/channel resident in HBM (the stream continues across passes), "
                                    f"{ns} stages instantiated ({reached} with count>=1)",
-                       "fft_size": n, "channels": C * world, "samples_per_step_per_channel": T,
+                       "fft_size": n, "channels": C * world, "channels_per_gpu": C,
+                       "samples_per_pass_per_channel": T, "passes_per_step": P,
+                       "samples_per_step_per_channel": T * P,
                        "stages": ns, "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
