@@ -46,6 +46,13 @@ __device__ unsigned long long g_stamps[16];
     } while (0)
 #endif
 
+// -DPSDK_ABL=<bits>: TIMING-ONLY ablations (wrong results; tools/build_variants.sh), never in the shipped build:
+//   1 no pass-1 twiddles   2 no carried-state copy in/out   4 no decimator   8 no FFT passes 1 and 2
+//   16 no stage A   32 no stage C   64 no look-ahead loads
+#ifndef PSDK_ABL
+#define PSDK_ABL 0
+#endif
+
 template <int N>
 struct FusedGeo : FusedDec<N> {
     using T = TeamFft<N>;
@@ -253,12 +260,22 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         // gets its few issue slots at once instead of queueing behind the butterflies of the other
         // wavefronts of the SIMD: +3-4 %)
         PSDK_STAMP(0);
+#ifdef PSDK_STAMPS
+        if constexpr (TEAM == 64) { // diagnostic: how long the wave waits for the look-ahead loads of this pair
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PSDK_STAMP(1);
+        }
+#endif
         __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
+        if constexpr (!(PSDK_ABL & 4)) {
+        if constexpr (!(PSDK_ABL & 2)) {
 #pragma unroll
         for (int r = 0; r < HR; ++r) // carried state -> fronts of the A and B arrays
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
                 sf[h_pack[r] & 0xFFFFu] = HREG ? hreg[r] : hs[tl + TEAM * r];
-        if constexpr (TEAM == 64) {
+        }
+        if constexpr (PSDK_ABL & 16) {
+        } else if constexpr (TEAM == 64) {
             // Stage A straight from the registers the loads filled: lane tl holds samples
             // 4tl..4tl+3 of each 256-sample piece = (xe[2tl], xo[2tl], xe[2tl+1], xo[2tl+1]); the
             // outputs (2tl, 2tl+1) of a piece need the three lanes below, fetched with DPP
@@ -331,15 +348,18 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         }
         wave_sync();
         PSDK_STAMP(3);
-        { // stage C: N/8 outputs, two per lane, straight to the next stage's stream
+        if constexpr (!(PSDK_ABL & 32)) { // stage C: N/8 outputs, two per lane, straight to the next stage's stream
             float y0, y1;
             hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tl, tc, y0, y1);
             *reinterpret_cast<f2 *>(o + 2 * tl) = {y0, y1};
         }
+        if constexpr (!(PSDK_ABL & 2)) {
 #pragma unroll
         for (int r = 0; r < HR; ++r) // tails of A and B -> carried state
             if ((h_pack[r] & 0xFFFFu) != 0xFFFFu)
                 (HREG ? hreg[r] : hs[tl + TEAM * r]) = sf[h_pack[r] >> 16];
+        }
+        } // PSDK_ABL & 4
         wave_sync(); // the frame is reused by the FFT
         PSDK_STAMP(4);
         __builtin_amdgcn_s_setprio(0);
@@ -398,10 +418,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
           // waited for at the branch's end, which would expose the HBM latency once per pair.
             const float4 *src = more ? cnext : safe;
             safe = src;
+            if constexpr (!(PSDK_ABL & 64)) {
             up[0] = src[2 * TEAM];
             up[1] = src[3 * TEAM];
             lo[0] = src[N / 4];
             lo[1] = src[N / 4 + TEAM];
+            }
         }
         PSDK_STAMP(5);
 #ifdef PSDK_EXTRA_VALU // sensitivity probe: dummy VALU work per pair (never defined in the shipped build)
@@ -428,13 +450,18 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         T::store0(tl, v, frame);
         wave_sync();
         PSDK_STAMP(6);
+        if constexpr (!(PSDK_ABL & 8)) {
         T::load1(tl, v, frame);
-        T::pass1(tl, v, s_tw1);
+        if constexpr (PSDK_ABL & 1)
+            Dft<T::R1>::run(v);
+        else
+            T::pass1(tl, v, s_tw1);
         T::store1(tl, v, frame); // in place: each lane rewrites exactly what it read
         wave_sync();
         PSDK_STAMP(7);
         T::load2(tl, v, frame);
         T::pass2(v);
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));

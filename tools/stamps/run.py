@@ -25,7 +25,7 @@ bank.sync()
 out = (C.c_ulonglong * 16)()
 rc = L.psdc_debug_stamps(out)
 assert rc == 0, rc
-names = ["(between pairs)", "dec: state+x -> LDS", "dec: stage A", "dec: stage B", "dec: stage C + state save",
+names = ["(between pairs)", "dec: state+x -> LDS | N=1024: wait for the look-ahead loads", "dec: stage A", "dec: stage B", "dec: stage C + state save",
          "detrend/window -> v", "pass0 + store0", "load1 + pass1 + store1", "load2 + pass2 + |Z|^2"]
 run = out[12]
 tot = sum(out[k] for k in range(9))
