@@ -333,15 +333,22 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 dp.eb = eamp.next(job);
             }
         }
+        // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one
+        // exposed L2 round trip per pair where reading all table entries at their uses was nineteen.  (Issuing the
+        // batch before the decimator instead hides that one as well but keeps 26 more registers live across it:
+        // measured slower at every size, and much slower at N = 16384, whose 1024 threads spill.)
+        typename T::Seeds sd[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
             const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
-            window_pair<N, DETREND, EWMA, true>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wp[0],
-                                          wp[TEAM], wp[2 * TEAM], wp[3 * TEAM], dp);
+            const float4 wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
+            sd[v] = T::load_seeds(tl, tw0p);
+            window_pair<N, DETREND, EWMA, true>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
+                                          wq2, wq3, dp);
             // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
             // go one after the other between two barriers)
-            T::pass0(tl, vv[v], tw0p);
+            T::pass0(tl, vv[v], sd[v]);
             T::store0(tl, vv[v], frame);
             lane_fence();
         }
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadA(tp + THREADS * v, vv[v], frame);
-            T::passA(tp + THREADS * v, vv[v], twap);
+            T::passA(tp + THREADS * v, vv[v], T::load_seeds_a(tp + THREADS * v, twap));
             T::storeA(tp + THREADS * v, vv[v], frame);
             lane_fence();
         }

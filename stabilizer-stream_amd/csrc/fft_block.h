@@ -1,7 +1,7 @@
 // fft_block.h -- N-point forward complex FFT by a whole workgroup of N/16
 // threads (N = 2048 ... 16384 -> 128 ... 1024 threads), 16 elements per thread,
 // radix (4, RA, RB, 16) decimation in frequency with RA*RB*16 = N/4, three
-// exchanges through a padded LDS frame (physical = idx + idx/16).
+// exchanges through a padded LDS frame (physical = idx + idx/16).  RA = 8 or 16.
 //
 // Same idea as fft_team.h one size class up: thread tl's pass-0 butterflies work
 // on n = 4 tl + c + (N/4) m, i.e. on what four 16-byte loads deliver.  After the
@@ -37,14 +37,44 @@ struct BlockFft {
         return tl / (RA * RB) + 4 * (r / RB) + 4 * RA * (r % RB) + 4 * RA * RB * q;
     }
 
+    // The twiddles of passes 0 and 1 come from global tables (tw0 [c][tl] = W_N^(4 tl + c), twa [(q-1)][s] =
+    // W_L1^(s q): too large for the LDS beside the frame).  A lane reads only three SEEDS of them per pair --
+    // W_N^(4 tl), W_L1^s, W_L1^(4 s) -- plus three uniform entries W_N^c (scalar loads), all issued together at
+    // the top of the pair so that they are in flight during the decimator, and forms the rest by
+    // multiplication (at most three factors deep: ~2e-7 relative, below the rounding of the butterflies).
+    // Reading all 4 + 15 entries instead cost the workgroup-level kernels most of their time: under the
+    // 128-register budget the backend issued them one at a time, each an exposed L2 round trip (19 dependent
+    // vmcnt(0) waits per pair in the N = 4096 listing; SQ_WAIT_ANY 42 % of wave time, profiles/r02b_n4096_sq.json).
+    struct Seeds {
+        cf w0;       // W_N^(4 tl)
+        cf wc[3];    // W_N^1, W_N^2, W_N^3 (the same for every lane)
+    };
+    struct SeedsA {
+        cf a1, a4;   // W_L1^s, W_L1^(4 s), s = tl % SA
+    };
+    static PSDK_HD Seeds load_seeds(int tl, const cf *tw0)
+    {
+        Seeds sd;
+        sd.w0 = tw0[tl];
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+            sd.wc[c - 1] = tw0[c * TEAM];
+        return sd;
+    }
+    static PSDK_HD SeedsA load_seeds_a(int tl, const cf *twa)
+    {
+        const int s = tl % SA;
+        return {twa[s], twa[3 * SA + s]};
+    }
+
     // pass 0 (as in fft_team.h): v[4m + c] = z[4 tl + c + L1 m] -> v[4q + c] = output q of s = 4 tl + c
-    static PSDK_HD void pass0(int tl, cf *v, const cf *tw0)
+    static PSDK_HD void pass0(int tl, cf *v, const Seeds &sd)
     {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             cf b[4] = {v[c], v[4 + c], v[8 + c], v[12 + c]};
             Dft<4>::run(b);
-            const cf w1 = tw0[c * TEAM + tl];
+            const cf w1 = c == 0 ? sd.w0 : cmul(sd.w0, sd.wc[c > 0 ? c - 1 : 0]); // W_N^(4 tl + c)
             const cf w2 = cmul(w1, w1);
             const cf w3 = cmul(w2, w1);
             v[c] = b[0];
@@ -80,16 +110,26 @@ struct BlockFft {
             for (int m = 0; m < RA; ++m)
                 v[RA * i + m] = lds_ld(base + STEP0 * (TEAM / SA) * i + STEPA * m);
     }
-    // twa[(q-1) * SA + s] = W_L1^(s q)
-    static PSDK_HD void passA(int tl, cf *v, const cf *twa)
+    // twiddles W_L1^(s q), q = 1 ... RA - 1, from the seeds a1 = W^s and a4 = W^(4 s): W^(4k + j) = W^(4k) W^j
+    static PSDK_HD void passA(int tl, cf *v, const SeedsA &sd)
     {
-        const int s = tl % SA;
+        const cf w1 = sd.a1, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
 #pragma unroll
         for (int i = 0; i < NBA; ++i) {
             Dft<RA>::run(v + RA * i);
+            cf wb = sd.a4; // W^(4 k s), k = 1, 2, 3
+            v[RA * i + 1] = cmul(v[RA * i + 1], w1);
+            v[RA * i + 2] = cmul(v[RA * i + 2], w2);
+            v[RA * i + 3] = cmul(v[RA * i + 3], w3);
 #pragma unroll
-            for (int q = 1; q < RA; ++q)
-                v[RA * i + q] = cmul(v[RA * i + q], twa[(q - 1) * SA + s]);
+            for (int k = 1; 4 * k < RA; ++k) {
+                v[RA * i + 4 * k] = cmul(v[RA * i + 4 * k], wb);
+                v[RA * i + 4 * k + 1] = cmul(v[RA * i + 4 * k + 1], cmul(wb, w1));
+                v[RA * i + 4 * k + 2] = cmul(v[RA * i + 4 * k + 2], cmul(wb, w2));
+                v[RA * i + 4 * k + 3] = cmul(v[RA * i + 4 * k + 3], cmul(wb, w3));
+                if (4 * (k + 1) < RA)
+                    wb = cmul(wb, sd.a4);
+            }
         }
     }
     static PSDK_HD void storeA(int tl, const cf *v, cf *frame)

@@ -257,10 +257,12 @@ static int check_block()
         for (int m = 0; m < 4; ++m)
             for (int c = 0; c < 4; ++c)
                 regs[t][4 * m + c] = z[4 * t + c + (N / 4) * m];
-    for (int t = 0; t < TEAM; ++t) T::pass0(t, regs[t].data(), tw0.data());
+    std::vector<typename T::Seeds> seeds(TEAM); // what a lane reads of the two global tables (the rest by products)
+    for (int t = 0; t < TEAM; ++t) seeds[t] = T::load_seeds(t, tw0.data());
+    for (int t = 0; t < TEAM; ++t) T::pass0(t, regs[t].data(), seeds[t]);
     for (int t = 0; t < TEAM; ++t) T::store0(t, regs[t].data(), frame.data());
     for (int t = 0; t < TEAM; ++t) T::loadA(t, regs[t].data(), frame.data());
-    for (int t = 0; t < TEAM; ++t) T::passA(t, regs[t].data(), twa.data());
+    for (int t = 0; t < TEAM; ++t) T::passA(t, regs[t].data(), T::load_seeds_a(t, twa.data()));
     for (int t = 0; t < TEAM; ++t) T::storeA(t, regs[t].data(), frame.data());
     for (int t = 0; t < TEAM; ++t) T::loadB(t, regs[t].data(), frame.data());
     for (int t = 0; t < TEAM; ++t) T::passB(t, regs[t].data(), twb.data());
