@@ -242,12 +242,11 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::BO + 29 + u] = y1;
         }
         __syncthreads();
+        f2 yc[VT]; // stage C: N/8 outputs, two per lane; stored further down, see there
 #pragma unroll
-        for (int r = 0; r < VT; ++r) { // stage C: N/8 outputs, two per lane
+        for (int r = 0; r < VT; ++r) {
             const int u = tp + THREADS * r;
-            float y0, y1;
-            hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * u, tc, y0, y1);
-            *reinterpret_cast<f2 *>(o + 2 * u) = {y0, y1};
+            hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * u, tc, yc[r].x, yc[r].y);
         }
         if ((h_pack & 0xFFFFu) != 0xFFFFu)
             hs[tp] = sf[h_pack >> 16];
@@ -352,9 +351,24 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             T::store0(tl, vv[v], frame);
             lane_fence();
         }
-        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT; issued
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            T::loadA(tp + THREADS * v, vv[v], frame);
+            T::passA(tp + THREADS * v, vv[v], T::load_seeds_a(tp + THREADS * v, twap));
+            T::storeA(tp + THREADS * v, vv[v], frame);
+            lane_fence();
+        }
+        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during passes B and C and the
+          // next decimator's first stage -- AFTER pass A's twiddle seeds (vmcnt retires loads in order: a wait for the
+          // seeds behind these would wait for HBM); issued
           // unconditionally (after the last pair: re-reads of pieces read before, unused) so that
           // the compiler does not wait for them at the end of a branch
+            // (the decimator's outputs leave here too: a store issued in stage C would sit in front of the table
+            // loads in the same in-order counter, and the wait for the window would wait for its write as well)
+#pragma unroll
+            for (int r = 0; r < VT; ++r)
+                *reinterpret_cast<f2 *>(o + 2 * (tp + THREADS * r)) = yc[r];
             const float4 *src = more ? cnext : safe;
             safe = src;
 #pragma unroll
@@ -365,14 +379,6 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 lo[v][0] = c[N / 4];
                 lo[v][1] = c[N / 4 + TEAM];
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            T::loadA(tp + THREADS * v, vv[v], frame);
-            T::passA(tp + THREADS * v, vv[v], T::load_seeds_a(tp + THREADS * v, twap));
-            T::storeA(tp + THREADS * v, vv[v], frame);
-            lane_fence();
         }
         __syncthreads();
 #pragma unroll
