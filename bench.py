@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--detrend", default="none")
     ap.add_argument("--coalesce", type=int, default=None,
                     help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 8)")
+    ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
@@ -202,6 +203,8 @@ def main():
     bank.set_detrend(pkg.Detrend[args.detrend.upper()])
     if args.coalesce is not None:
         bank.configure(coalesce=args.coalesce)
+    if args.min_pairs is not None:
+        bank.configure(min_pairs=args.min_pairs)
     if args.avg:
         lim, cnt = (int(v) for v in args.avg.split(","))
         bank.set_avg(pkg.AvgOpts(lim, cnt))
@@ -232,6 +235,8 @@ def main():
         scratch.set_detrend(pkg.Detrend[args.detrend.upper()])
         if args.coalesce is not None:
             scratch.configure(coalesce=args.coalesce)
+        if args.min_pairs is not None:
+            scratch.configure(min_pairs=args.min_pairs)
         scratch.configure(profile=True)  # rocprofv3 --stats sees these launches too: counted in *_whole_process
         tw = time.perf_counter()
         while (time.perf_counter() - tw) * 1e3 < args.clock_warm_ms:

@@ -64,6 +64,9 @@ extern "C" {
                              * still busy with earlier ones (1..16, default 8; 1 = every span its own round;
                              * -k: hold k spans back even on an idle device -- for tests) */
 #define PSDC_OPT_PROFILE 2 /* 1: time the dominant kernel with HIP events (psdc_profile_read) */
+#define PSDC_OPT_MIN_PAIRS 4 /* segment pairs a decimated stage (k >= 1) collects before it issues work on the ingest
+                              * path (default 32 x teams per workgroup: 256 at n = 1024; 0 = issue at once).  Read-outs,
+                              * psdc_flush and psdc_sync always issue everything: results do not depend on it. */
 
 typedef struct psdc_handle psdc_handle;
 

@@ -32,7 +32,7 @@ U32_MAX = 0xFFFFFFFF
 PSDC_OK = 0
 ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNIMPLEMENTED = -1, -2, -3, -4
 ERR_FRAME_HEADER, ERR_FRAME_FORMAT, ERR_FRAME_SIZE, ERR_CAPACITY = -5, -6, -7, -8
-OPT_QUANTUM, OPT_PROFILE, OPT_COALESCE = 1, 2, 3
+OPT_QUANTUM, OPT_PROFILE, OPT_COALESCE, OPT_MIN_PAIRS = 1, 2, 3, 4
 
 
 class PsdError(RuntimeError):
@@ -296,7 +296,9 @@ class PsdCascadeBank:
     def reset(self):
         self._ck(self._L.psdc_reset(self._h))
 
-    def configure(self, quantum=None, profile=None, coalesce=None):
+    def configure(self, quantum=None, profile=None, coalesce=None, min_pairs=None):
+        if min_pairs is not None:
+            self._ck(self._L.psdc_configure(self._h, OPT_MIN_PAIRS, int(min_pairs)))
         if quantum is not None:
             self._ck(self._L.psdc_configure(self._h, OPT_QUANTUM, int(quantum)))
         if profile is not None:

@@ -137,6 +137,7 @@ struct psdc_handle {
     size_t quantum = (size_t)1 << 22;
     uint32_t coalesce = 8; // zero-copy spans per channel held back while the device is busy (1 = none)
     uint32_t stage_limit = MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
+    uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
     bool coalesce_always = false; // hold them back even when the device is idle (tests)
     bool profile = false;
     std::vector<ProfEvents> prof_pending;
@@ -392,7 +393,20 @@ int add_stage(psdc_handle *h, Channel &c)
 // writes before that point; host-visible state never waits for it (read-outs drain first).
 int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
 {
-    const size_t nr = h->pend_red.size(), np = h->pend_tail.size(), nt = np + extra.size();
+    // a copy job is one workgroup of post_kernel: long tails (a stage that collects a batch keeps up to
+    // PSDC_OPT_MIN_PAIRS pairs pending) are cut into pieces so that the launch does not wait on one workgroup
+    constexpr int kPiece = 16384;
+    std::vector<TailJob> tails;
+    tails.reserve(h->pend_tail.size() + extra.size());
+    auto add_tail = [&](const TailJob &t) {
+        for (int o = 0; o < t.count; o += kPiece)
+            tails.push_back({t.src + o, t.dst + o, std::min(kPiece, t.count - o)});
+    };
+    for (const TailJob &t : h->pend_tail)
+        add_tail(t);
+    for (const TailJob &t : extra)
+        add_tail(t);
+    const size_t nr = h->pend_red.size(), nt = tails.size();
     for (size_t ri = 0, ti = 0; ri < nr || ti < nt;) {
         RedBatch rb{};
         rb.n = (int)h->n;
@@ -400,7 +414,7 @@ int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
             rb.jobs[rb.njobs++] = h->pend_red[ri];
         TailBatch tb{};
         for (; ti < nt && tb.njobs < MAX_JOBS; ++ti)
-            tb.jobs[tb.njobs++] = ti < np ? h->pend_tail[ti] : extra[ti - np];
+            tb.jobs[tb.njobs++] = tails[ti];
         HIPCHK(h, launch_post(rb, tb, h->stream));
     }
     h->pend_red.clear();
@@ -625,6 +639,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             // other round; read-outs (all == true) issue everything
             if (!all && fast_ok && k >= 1 && ((j_new - s.segs) & 1))
                 j_new -= 1;
+            // ... and a decimated stage waits until it has a worthwhile batch: every job of a launch occupies at
+            // least one resident workgroup for the whole launch, and the deep stages of many channels (a handful
+            // of pairs per round each) otherwise hold ~10 % of the GPU's workgroup slots nearly idle (8 channels:
+            // 578 -> 6xx GS/s).  The pending samples simply stay in the stage's stream buffer (<= 1 MiB).
+            if (!all && fast_ok && k >= 1 && j_new - s.segs < 2 * (uint64_t)h->min_pairs)
+                j_new = s.segs;
             if (j_new == s.segs)
                 continue;
             Work w;
@@ -1313,6 +1333,7 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
     h->n_channels = n_channels;
     h->device = device;
     h->ch.resize(n_channels);
+    h->min_pairs = fused_supported((int)n) ? 32u * (uint32_t)std::max(1, fused_pairs_per_block((int)n, 1)) : 0u;
 
     // window table exactly as the reference builds it (src/psd.rs:44-48), twiddles in f64
     std::vector<float> win(n);
@@ -1500,6 +1521,12 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
             return rc;
         h->coalesce = (uint32_t)k;
         h->coalesce_always = value < 0;
+        return PSDC_OK;
+    }
+    case PSDC_OPT_MIN_PAIRS: {
+        if (value < 0 || value > (1 << 20))
+            return fail(h, PSDC_ERR_ARG, "min_pairs out of range");
+        h->min_pairs = (uint32_t)value;
         return PSDC_OK;
     }
     default:
@@ -2051,6 +2078,7 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->coalesce = h->coalesce;
     o->coalesce_always = h->coalesce_always;
     o->stage_limit = h->stage_limit;
+    o->min_pairs = h->min_pairs;
     auto bad = [&](const char *what) -> psdc_handle * {
         fail(nullptr, PSDC_ERR_DEVICE, std::string("psdc_clone: ") + what);
         psdc_destroy(o);
