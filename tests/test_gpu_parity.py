@@ -1073,3 +1073,62 @@ def test_count_past_two_to_the_32(pkg, gpu_required):
     psd, br = g.psd(0)
     assert np.all(np.isfinite(psd)) and abs(float(np.mean(psd[br[-1].start + 1:-1])) * 0.5 - 1.0) < 1e-3
     g.close()
+
+
+def test_new_entry_points_argument_errors(pkg, gpu_required):
+    """Misuse of the round-2 entry points returns PSDC_ERR_* (the reference would panic), never crashes."""
+    import ctypes as C
+    L = pkg.lib()
+    assert L.psdc_stage_create(100, 1, 0) is None  # unsupported N
+    assert L.psdc_stage_process(None, None, 0, None, 0, None) == pkg.ERR_ARG
+    s = pkg.Psd(256)
+    assert s.count() == 0 and s.gain() == 0.0 and s.buf().size == 0 and np.all(s.spectrum() == 0)  # a fresh Psd
+    assert s.process(np.zeros(0, dtype=np.float32)).size == 0
+    with pytest.raises(pkg.PsdError) as e:
+        s.set_detrend(pkg.Detrend.LINEAR)
+    assert e.value.code == pkg.ERR_UNIMPLEMENTED
+    y = s.process(pkg.noise_host(255, 1))
+    assert y.size == 0 and s.count() == 0 and s.buf().size == 255  # one sample short of a segment
+    y = s.process(pkg.noise_host(1, 2))
+    assert s.count() == 1 and y.size == 0 and s.buf().size == 128  # first segment: 32 outputs, all inside the drain of 35
+    y = s.process(pkg.noise_host(128, 3))
+    assert s.count() == 2 and y.size == 48 - 35
+    s.close()
+    g = pkg.PsdCascadeBank(1024)
+    assert L.psdc_record_consumed(g._h, None) == pkg.ERR_ARG
+    assert L.psdc_process_device_after(g._h, 3, None, 16, None) == pkg.ERR_ARG  # channel out of range
+    assert L.psdc_process_device_after(g._h, 0, None, 16, None) == pkg.ERR_ARG  # null input
+    assert L.psdc_process_device_after(g._h, 0, None, 0, None) == 0            # empty input: nothing happens
+    with pytest.raises(pkg.PsdError):
+        g.configure(min_pairs=-1)
+    g.configure(min_pairs=0)
+    g.close()
+    rms = C.c_float()
+    assert L.psdc_trace_plot(None, None, 5, 1.0, 0, 0.0, 1.0, C.byref(rms), None, 0, None) == pkg.ERR_ARG
+
+
+def test_min_pairs_does_not_change_results(pkg, ora, gpu_required):
+    """PSDC_OPT_MIN_PAIRS only decides WHEN a decimated stage issues its segments on the ingest path: any setting,
+    with read-outs in between, gives the oracle's counters exactly and spectra within the pure tolerance."""
+    import torch
+    n = 1024
+    x = pkg.noise_host((1 << 23) + 8 * 555, seed=321)
+    d = torch.from_numpy(x).cuda()
+    spectra = []
+    for mp in (0, 1, 256, 5000):
+        g = pkg.PsdCascadeBank(n)
+        g.configure(min_pairs=mp)
+        cuts = [0, 1 << 21, (1 << 21) + 40 * n, 3 << 21, x.size]
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            g.process_device(0, d.data_ptr() + 4 * a, b - a)
+            if i == 1:
+                ref = ora.PsdCascade(n, "f64")
+                ref.process(x[:b])
+                for k in range(ref.num_stages):  # a read-out issues everything that is complete
+                    assert g.stage_info(0, k) == ref.stage_info(k), (mp, k)
+        check_against_oracle(pkg, ora, g, [x], n, what=f"min_pairs {mp}", pure_min_count=4)
+        spectra.append([g.stage_spectrum(0, k) for k in range(g.num_stages(0))])
+        g.close()
+    for sp in spectra[1:]:
+        for a, b in zip(spectra[0], sp):
+            assert np.allclose(a, b, rtol=2e-6, atol=1e-6 * float(np.mean(a)))
