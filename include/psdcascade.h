@@ -177,6 +177,13 @@ int psdc_record_consumed(psdc_handle *h, void *consumed_event);
 int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
                                size_t n_frames, size_t *n_ok);
 
+/* The same for frames that already sit in device memory (a capture buffer filled by a NIC / another kernel): headers
+ * are validated and the Loss counters formed by two small kernels, the payloads de-interleaved straight into the
+ * stage-0 streams.  The producer of d_frames must have completed; the frames are read before the call returns
+ * only as far as the header scan -- keep them valid until psdc_sync() / a read-out / a psdc_record_consumed event. */
+int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size,
+                                      size_t n_frames, size_t *n_ok);
+
 /* Loss (src/loss.rs:3-26): sequence-gap accounting over the frames ingested by
  * psdc_process_adcdac_frames.  received counts batches; dropped the batches missing
  * between consecutive frames (u32 wrapping_sub); gaps are counted, never zero-filled. */

@@ -201,6 +201,7 @@ def lib():
     f("psdc_process_device_after", i32, [H, u32, C.c_void_p, sz, C.c_void_p])
     f("psdc_record_consumed", i32, [H, C.c_void_p])
     f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
+    f("psdc_process_adcdac_frames_device", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_loss_read", i32, [H, C.POINTER(_CLoss), i32])
     f("psdc_flush", i32, [H])
     f("psdc_sync", i32, [H])
@@ -247,7 +248,7 @@ EXPORTS = [
     "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_read_channel", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
-    "psdc_process_device_after", "psdc_record_consumed", "psdc_trace_plot",
+    "psdc_process_device_after", "psdc_record_consumed", "psdc_trace_plot", "psdc_process_adcdac_frames_device",
     "psdc_stage_create", "psdc_stage_destroy", "psdc_stage_clone", "psdc_stage_set_avg", "psdc_stage_set_detrend",
     "psdc_stage_process", "psdc_stage_process_device", "psdc_stage_get_spectrum", "psdc_stage_get_count",
     "psdc_stage_get_gain", "psdc_stage_get_buf", "psdc_stage_last_error",
@@ -339,6 +340,14 @@ class PsdCascadeBank:
         ok = C.c_size_t(0)
         rc = self._L.psdc_process_adcdac_frames(self._h, buf.ctypes.data_as(C.c_void_p), frame_size,
                                                 n_frames, C.byref(ok))
+        if rc < 0:
+            _raise(rc, self._h)
+        return ok.value
+
+    def process_adcdac_frames_device(self, ptr, frame_size, n_frames):
+        """Frames resident in device memory at address `ptr`; returns the number of frames ingested."""
+        ok = C.c_size_t(0)
+        rc = self._L.psdc_process_adcdac_frames_device(self._h, C.c_void_p(ptr), frame_size, n_frames, C.byref(ok))
         if rc < 0:
             _raise(rc, self._h)
         return ok.value

@@ -154,4 +154,11 @@ hipError_t launch_copy_out(float *h_dst, const float *d_src, size_t count, hipSt
 hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,
                          float *dst0, float *dst1, float *dst2, float *dst3, hipStream_t s);
 
+// device-resident frames (out: device memory, zeroed): header checks of every frame (out[0] <- max ~(index << 2 | code)
+// over the bad ones) and the
+// Loss counters over the first n (out[1] += batches, out[2] += sequence gaps, out[3] = first seq | next seq << 32)
+hipError_t launch_adcdac_scan(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok,
+                              unsigned long long *out, hipStream_t s);
+hipError_t launch_adcdac_loss(const uint8_t *frames, size_t frame_size, size_t n, unsigned long long *out, hipStream_t s);
+
 } // namespace psdk

@@ -421,9 +421,85 @@ __global__ __launch_bounds__(256) void adcdac_kernel(const uint8_t *__restrict__
     }
 }
 
+// Device-resident frames: Header::parse (src/de/frame.rs:25-37) + the AdcDac size checks (src/de/data.rs:22-25) of
+// every frame, in the reference's order; out[0] <- max over the bad frames of ~(index << 2 | code) (code 1
+// InvalidHeader, 2 UnknownFormat, 3 PayloadSize / batches mismatch), i.e. the FIRST bad frame; 0 if all are good.
+__global__ __launch_bounds__(256) void adcdac_scan_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames,
+                                                          int batches, int payload_ok, unsigned long long *out)
+{
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (size_t)gridDim.x * 256) {
+        const uint8_t *p = frames + f * frame_size;
+        int code = 0;
+        if (p[0] != 0x7b || p[1] != 0x05)
+            code = 1;
+        else if (p[2] != 1)
+            code = 2;
+        else if (!payload_ok || (int)p[3] != batches)
+            code = 3;
+        if (code)
+            atomicMax(out, ~(((unsigned long long)f << 2) | (unsigned long long)code));
+    }
+}
+
+// Loss::update (src/loss.rs:11-26) over frames [0, n): out[1] += batches, out[2] += the u32 sequence gaps between
+// consecutive frames (wrapping_sub), out[3] <- seq of frame 0 (low half) and seq + batches of the last (high half).
+__global__ __launch_bounds__(256) void adcdac_loss_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n,
+                                                          unsigned long long *out)
+{
+    auto seq_of = [&](size_t f) {
+        const uint8_t *p = frames + f * frame_size;
+        return (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+    };
+    unsigned long long rec = 0, drop = 0;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n; f += (size_t)gridDim.x * 256) {
+        const uint32_t b = frames[f * frame_size + 3];
+        rec += b;
+        if (f > 0)
+            drop += (uint32_t)(seq_of(f) - (seq_of(f - 1) + (uint32_t)frames[(f - 1) * frame_size + 3]));
+        if (f == 0)
+            atomicOr(out + 3, (unsigned long long)seq_of(0));
+        if (f == n - 1)
+            atomicOr(out + 3, (unsigned long long)(uint32_t)(seq_of(f) + b) << 32);
+    }
+    __shared__ unsigned long long s_rec[256], s_drop[256];
+    s_rec[threadIdx.x] = rec;
+    s_drop[threadIdx.x] = drop;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_rec[threadIdx.x] += s_rec[threadIdx.x + o];
+            s_drop[threadIdx.x] += s_drop[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 1, s_rec[0]);
+        atomicAdd(out + 2, s_drop[0]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+
+hipError_t launch_adcdac_scan(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok,
+                              unsigned long long *out, hipStream_t s)
+{
+    if (n_frames == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n_frames + 255) / 256);
+    hipLaunchKernelGGL(adcdac_scan_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, payload_ok, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_adcdac_loss(const uint8_t *frames, size_t frame_size, size_t n, unsigned long long *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(adcdac_loss_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n, out);
+    return hipGetLastError();
+}
 
 int welch_segments_per_tile(int n)
 {

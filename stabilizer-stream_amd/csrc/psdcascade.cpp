@@ -113,6 +113,7 @@ struct psdc_handle {
     std::vector<Channel> ch;
     float *d_spectra = nullptr; // [n_channels][MAX_STAGES][n] accumulators, one slab
     float *h_read = nullptr;    // pinned bounce buffer for read-outs (MAX_STAGES * n floats)
+    unsigned long long *d_scan = nullptr; // 4 words: verdict of the device-side frame header scan + Loss sums
     float *d_pool = nullptr;    // [n_channels][MAX_STAGES][2][pool_cap] small stream buffers (deep stages)
     size_t pool_cap = 0;        // floats per pooled buffer
     bool idle = true;           // nothing ingested since the pipeline was last drained
@@ -1430,6 +1431,8 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_pool);
     if (h->h_read)
         (void)hipHostFree(h->h_read);
+    if (h->d_scan)
+        (void)hipFree(h->d_scan);
     for (int i = 0; i < 2; ++i) {
         if (h->d_frames[i])
             (void)hipFree(h->d_frames[i]);
@@ -1814,6 +1817,121 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                 HIPCHK(h, hipEventCreateWithFlags(&h->frames_dec_ev[b], hipEventDisableTiming));
             HIPCHK(h, hipEventRecord(h->frames_dec_ev[b], h->stream));
             h->frames_dec_pending[b] = true;
+            for (int ci = 0; ci < 4; ++ci) {
+                h->ch[ci].st[0].total += per_ch;
+                h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
+                h->ch[ci].submitted = true;
+            }
+            rc = advance(h);
+            if (rc)
+                return rc;
+        }
+    }
+    if (n_ok)
+        *n_ok = good;
+    if (bad != PSDC_OK)
+        return fail(h, bad,
+                    bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
+                    : bad == PSDC_ERR_FRAME_FORMAT ? "Unknown or non-AdcDac format ID"
+                                                   : "Payload size");
+    return PSDC_OK;
+}
+
+int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size, size_t n_frames,
+                                      size_t *n_ok)
+{
+    if (n_ok)
+        *n_ok = 0;
+    int rc = check_channel(h, 0);
+    if (rc)
+        return rc;
+    ON_DEVICE(h, h->device);
+    if (h->n_channels < 4)
+        return fail(h, PSDC_ERR_ARG, "AdcDac frames carry four traces: need n_channels >= 4");
+    if (n_frames == 0)
+        return PSDC_OK;
+    if (!d_frames)
+        return fail(h, PSDC_ERR_ARG, "null input");
+    if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
+        return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
+    const size_t payload = frame_size - 8;
+    const int batches = (int)(payload / 64);
+    // order behind anything pending on these channels
+    bool pend = false;
+    for (int ci = 0; ci < 4; ++ci)
+        pend = pend || h->ch[ci].has_span() || h->ch[ci].submitted || h->ch[ci].fill;
+    if (pend) {
+        rc = flush_all(h);
+        if (rc)
+            return rc;
+    }
+    rc = wait_uploads(h);
+    if (rc)
+        return rc;
+    // headers are checked on the device (the frames are there) and the Loss counters summed there too, over all
+    // frames at first -- the common case has no bad frame -- and again over the accepted ones if there was one;
+    // the four words come back through the pinned read-out buffer: {~(first bad frame << 2 | error) or 0, batches
+    // received, sequence gaps, first seq | next seq << 32}
+    if (!h->d_scan)
+        HIPCHK(h, hipMalloc(&h->d_scan, 4 * sizeof(unsigned long long)));
+    const unsigned long long *res = reinterpret_cast<const unsigned long long *>(h->h_read);
+    auto scan = [&](size_t n_loss, bool check) -> int {
+        HIPCHK(h, hipMemsetAsync(h->d_scan, 0, 4 * sizeof(unsigned long long), h->stream));
+        if (check)
+            HIPCHK(h, launch_adcdac_scan(d_frames, frame_size, n_frames, batches, payload % 64 == 0, h->d_scan, h->stream));
+        HIPCHK(h, launch_adcdac_loss(d_frames, frame_size, n_loss, h->d_scan, h->stream));
+        HIPCHK(h, launch_copy_out(h->h_read, reinterpret_cast<const float *>(h->d_scan), 8, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PSDC_OK;
+    };
+    rc = scan(n_frames, true);
+    if (rc)
+        return rc;
+    size_t good = n_frames;
+    int bad = PSDC_OK;
+    if (res[0] != 0) {
+        const unsigned long long key = ~res[0];
+        good = (size_t)(key >> 2);
+        const int code = (int)(key & 3);
+        bad = code == 1 ? PSDC_ERR_FRAME_HEADER : code == 2 ? PSDC_ERR_FRAME_FORMAT : PSDC_ERR_FRAME_SIZE;
+        if (good) {
+            rc = scan(good, false);
+            if (rc)
+                return rc;
+        }
+    }
+    if (good) { // Loss::update over the accepted frames (src/loss.rs:11-26)
+        h->loss.received += res[1];
+        const uint32_t seq0 = (uint32_t)res[3], next = (uint32_t)(res[3] >> 32);
+        if (h->loss.have_seq)
+            h->loss.dropped += (uint32_t)(seq0 - h->loss.next_seq); // wrapping_sub
+        h->loss.dropped += res[2];
+        h->loss.next_seq = next;
+        h->loss.have_seq = 1;
+    }
+    if (good && batches > 0) {
+        h->idle = false;
+        // decoded into the stage-0 stream buffers in pieces of <= 2^24 samples per trace, each piece a round
+        const size_t piece_frames = std::max<size_t>(1, ((size_t)1 << 24) / ((size_t)batches * 8));
+        for (size_t f0 = 0; f0 < good; f0 += piece_frames) {
+            const size_t cnt = std::min(piece_frames, good - f0);
+            const size_t per_ch = cnt * (size_t)batches * 8;
+            float *dst[4];
+            for (int ci = 0; ci < 4; ++ci) {
+                Channel &c = h->ch[ci];
+                if (c.st.empty()) {
+                    rc = add_stage(h, c);
+                    if (rc)
+                        return rc;
+                }
+                StageState &s0 = c.st[0];
+                rc = ensure_room(h, s0, s0.total + per_ch);
+                if (rc)
+                    return rc;
+                dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
+            }
+            HIPCHK(h, launch_adcdac(d_frames + f0 * frame_size, frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3],
+                                    h->stream));
             for (int ci = 0; ci < 4; ++ci) {
                 h->ch[ci].st[0].total += per_ch;
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;

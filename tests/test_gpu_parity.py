@@ -1132,3 +1132,54 @@ def test_min_pairs_does_not_change_results(pkg, ora, gpu_required):
     for sp in spectra[1:]:
         for a, b in zip(spectra[0], sp):
             assert np.allclose(a, b, rtol=2e-6, atol=1e-6 * float(np.mean(a)))
+
+
+def test_adcdac_frames_device_resident(pkg, ora, gpu_required):
+    """psdc_process_adcdac_frames_device: the frames already sit in HBM -- headers checked and Loss counters formed
+    on the device (src/de/frame.rs:25-37, src/de/data.rs:22-25, src/loss.rs:11-26), payloads decoded into the four
+    cascades.  Same spectra as the oracle on the traces the reference decodes, same counters as the host-memory path,
+    including a sequence gap, the u32 wrap, and the three de::Error cases in the middle of a buffer."""
+    import torch
+    n, batches, nframes = 1024, 22, 9000
+    rng = np.random.default_rng(12)
+    raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8)) * 3000), -32768, 32767).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, batches, seq0=0xFFFFFF00)  # the sequence number wraps on the way
+    buf = np.frombuffer(data, dtype=np.uint8).copy().reshape(nframes, fs)
+    buf[5000:, 4:8] = (buf[5000:, 4:8].copy().view("<u4") + np.uint32(7 * batches)).view(np.uint8)  # 7 frames lost before #5000
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4)
+    assert g.process_adcdac_frames_device(d.data_ptr(), fs, 3000) == 3000
+    assert g.process_adcdac_frames_device(d.data_ptr() + 3000 * fs, fs, nframes - 3000) == nframes - 3000
+    hst = pkg.PsdCascadeBank(n, 4)
+    assert hst.process_adcdac_frames(buf.tobytes(), fs) == nframes
+    assert g.loss() == hst.loss() == {"received": nframes * batches, "dropped": 7 * batches}
+    traces = [[] for _ in range(4)]
+    for f in range(nframes):
+        st, seq, nb, tr = ora.adcdac_decode(buf[f].tobytes())
+        assert st == 0 and nb == batches
+        for c in range(4):
+            traces[c].append(tr[c])
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [np.concatenate(traces[c])], n, channel=c, what=f"device frames {pkg.ADCDAC_TRACES[c]}")
+        for k in range(g.num_stages(c)):
+            assert g.stage_info(c, k) == hst.stage_info(c, k)
+    # a bad frame in the middle: the frames before it are ingested, the error is the reference's
+    for pos, (byte, val, code) in enumerate([(0, 0x00, pkg.ERR_FRAME_HEADER), (2, 9, pkg.ERR_FRAME_FORMAT),
+                                             (3, batches + 1, pkg.ERR_FRAME_SIZE)]):
+        bad = buf[:40].copy()
+        bad[17 + pos, byte] = val
+        db = torch.from_numpy(bad.reshape(-1)).cuda()
+        g2 = pkg.PsdCascadeBank(n, 4)
+        with pytest.raises(pkg.FrameError) as e:
+            g2.process_adcdac_frames_device(db.data_ptr(), fs, 40)
+        assert e.value.code == code
+        assert g2.loss()["received"] == (17 + pos) * batches
+        info = g2.stage_info(0, 0)  # every sample of the accepted frames reached the cascade, none of the rejected ones
+        assert info["pending"] + info["count"] * (n // 2) == (17 + pos) * batches * 8
+        g2.close()
+    g3 = pkg.PsdCascadeBank(n, 2)
+    with pytest.raises(pkg.PsdError):
+        g3.process_adcdac_frames_device(d.data_ptr(), fs, 1)  # four traces need four channels
+    g3.close()
+    g.close()
+    hst.close()

@@ -20,5 +20,22 @@ for _ in range(reps):
 g.sync()
 dt = time.perf_counter() - t0
 samples = reps * raw.size
-print(f"frames path: {samples / dt / 1e6:.0f} MS/s over 4 traces ({len(data) * reps / dt / 1e9:.2f} GB/s of frame bytes), "
+print(f"frames path (host memory): {samples / dt / 1e6:.0f} MS/s over 4 traces ({len(data) * reps / dt / 1e9:.2f} GB/s of frame bytes), "
       f"{g.num_stages(0)} stages, loss {g.loss()}")
+# the same frames resident in HBM (psdc_process_adcdac_frames_device): BASELINE config 3 with the input already on the GPU
+import torch
+d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+torch.cuda.synchronize()
+g2 = pkg.PsdCascadeBank(n, 4)
+for _ in range(3):
+    g2.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+g2.sync()
+reps = 40
+t0 = time.perf_counter()
+for _ in range(reps):
+    g2.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+g2.sync()
+dt = time.perf_counter() - t0
+samples = reps * raw.size
+print(f"frames path (device memory): {samples / dt / 1e6:.0f} MS/s over 4 traces ({len(data) * reps / dt / 1e9:.2f} GB/s of frame bytes = "
+      f"{len(data) * reps / dt / 8e12:.3f} of the HBM roofline on the algorithmic bytes), {g2.num_stages(0)} stages, loss {g2.loss()}")
