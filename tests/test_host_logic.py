@@ -161,3 +161,19 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
     src = open(bench).read()
     assert src.index("launch_ranks(args, argv)") < src.index("import torch\n")  # launched before torch is imported
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/psdcascade.h is the drop-in boundary for a C / Rust-FFI / cgo caller: it must compile as strict C99 and
+    link against the library with a C compiler."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "psdcascade.h"\n'
+                   "int main(void) { psdc_break b; psdc_stage_stat s; psdc_loss l; psdc_profile p; psdc_stage *st = 0;\n"
+                   "  (void)b; (void)s; (void)l; (void)p; (void)st;\n"
+                   "  return psdc_abi_version() == PSDC_ABI_VERSION && psdc_hbf_response_length(3) == 35 ? 0 : 1; }\n")
+    exe = tmp_path / "hdr"
+    lib_dir = os.path.join(ROOT, "stabilizer-stream_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe), "-L", lib_dir, "-lpsdcascade", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0  # pure host entry points: no GPU needed
