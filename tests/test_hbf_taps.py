@@ -101,6 +101,10 @@ def test_cascade_meets_the_reference_pins():
     up = lambda h, k: np.kron(h, np.r_[1.0, np.zeros(k - 1)])[: (len(h) - 1) * k + 1]
     comp = np.convolve(np.convolve(ha, up(hb, 2)), up(hc, 4))
     assert len(comp) == 287  # 11 + 2*22 + 4*58 -> 286-sample halo
+    # `hbf_dec_response_length(3)` (src/psd.rs:149): idsp's rule (per stage 2M-1 output samples, n = n/2 + len_i) gives 35,
+    # which is also the length of the composite impulse response counted in OUTPUT samples, floor(287 / 8): the number of
+    # outputs the zero initial state still shapes -- what the one-time drain of src/psd.rs:255-260 is there to discard
+    assert FIX["hbf_dec_response_length_3"] == len(comp) // 8 == 35
     nfft = 1 << 16
     H = np.abs(np.fft.rfft(comp, nfft))
     f = np.arange(H.size) / nfft  # cycles per input sample; output Nyquist = 1/16
