@@ -15,6 +15,14 @@
 
 namespace psdk {
 
+// -DPSDK_ABL=256 (tools/build_variants.sh): TIMING-ONLY, wrong results -- the two FFT-internal workgroup barriers as
+// wave-level syncs.  N = 2048 / 4096: +-0 %, N = 16384: +3.7 %: the barriers are not what these kernels wait for.
+#if defined(PSDK_ABL) && (PSDK_ABL & 256)
+#define PSDK_FFT_BARRIER() wave_sync()
+#else
+#define PSDK_FFT_BARRIER() __syncthreads()
+#endif
+
 template <int N>
 struct BigGeo : FusedDec<N> {
     using T = BlockFft<N>;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 lo[v][1] = c[N / 4 + TEAM];
             }
         }
-        __syncthreads();
+        PSDK_FFT_BARRIER();
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadB(tp + THREADS * v, vv[v], frame);
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             T::storeB(tp + THREADS * v, vv[v], frame);
             lane_fence();
         }
-        __syncthreads();
+        PSDK_FFT_BARRIER();
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadC(tp + THREADS * v, vv[v], frame);
