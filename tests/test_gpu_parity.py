@@ -1183,3 +1183,52 @@ def test_adcdac_frames_device_resident(pkg, ora, gpu_required):
     g3.close()
     g.close()
     hst.close()
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 1024, 4096])
+@pytest.mark.parametrize("detrend", ["none", "mean"])
+def test_rectangular_window_sizes(pkg, ora, gpu_required, n, detrend):
+    """Window::rectangular() (src/psd.rs:24-32: no overlap, power 1, nenbw 1) at every size class -- the generic
+    two-pass kernels -- host-fed in odd chunks and device-fed, with a read-out in between."""
+    import torch
+    total = 60 * n + 8 * 37
+    x = make_signal(pkg, total, seed=700 + n, tone=0.4, dc=0.3)
+    g = pkg.PsdCascadeBank(n, window=pkg.Window.RECTANGULAR)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    cut = (total // 3) | 1
+    g.process(0, x[:cut])
+    assert g.stage_info(0, 0)["count"] == cut // n
+    d = torch.from_numpy(x[cut:]).cuda()
+    g.process_device(0, d.data_ptr(), total - cut)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, window="rect", what=f"rect N={n} {detrend}")
+    g.close()
+
+
+def test_sixty_four_channel_bank(pkg, ora, gpu_required):
+    """All 64 channels of BASELINE config 4 in ONE handle (what a single GPU would hold if the node had one): uneven
+    stream lengths, round-robin device spans; every channel against its own oracle cascade, and the bulk read-out
+    (shard.pack_readout -> stitch_gathered) equal to psd() channel by channel."""
+    import torch
+    from importlib import import_module
+    shard = import_module(pkg.__name__ + ".shard")
+    n, nch = 1024, 64
+    lens = [(1 << 19) + 4096 * (c % 7) + 8 * c for c in range(nch)]
+    xs = [pkg.noise_host(lens[c], seed=0x7654321 + c) for c in range(nch)]
+    ds = [torch.from_numpy(x).cuda() for x in xs]
+    g = pkg.PsdCascadeBank(n, nch)
+    span = 1 << 17
+    for off in range(0, max(lens), span):
+        for c in range(nch):
+            m = min(span, lens[c] - off)
+            if m > 0:
+                g.process_device(c, ds[c].data_ptr() + 4 * off, m)
+    for c in range(0, nch, 9):
+        check_against_oracle(pkg, ora, g, [xs[c]], n, channel=c, what=f"channel {c} of 64", pure_min_count=4)
+    spec, meta = shard.pack_readout(g, nch, n)
+    merged = shard.stitch_gathered(pkg, n, [spec], [meta], [nch])
+    for c in range(nch):
+        p, br = g.psd(c)
+        assert np.array_equal(merged[c][0], p)
+        plan = pkg.plan_counts(n, lens[c])
+        assert [b.count for b in reversed(br)] == [segs for _, segs, _ in plan]
+    g.close()
