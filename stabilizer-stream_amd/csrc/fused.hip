@@ -591,7 +591,8 @@ void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa)
 template <int N>
 static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
-    static_assert(FusedGeo<N>::LDS_BYTES <= 81920, "two workgroups per CU need <= 80 KiB of LDS each");
+    static_assert(FusedGeo<N>::LDS_BYTES * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES) <= 163840,
+                  "the workgroups of a CU (two of eight waves by default) share its 160 KiB of LDS");
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
 #define PSDK_FUSED_CASE(D)                                                                \
     case D:                                                                               \
