@@ -178,6 +178,7 @@ public:
     void set_detrend(Detrend d) { check(psdc_set_detrend(h_, static_cast<int>(d))); }
     void process(std::span<const float> x) { check(psdc_process(h_, 0, x.data(), x.size())); }
     void process_device(const float *d_x, size_t len) { check(psdc_process_device(h_, 0, d_x, len)); }
+    psdc_handle *handle() const { return h_; } // for the batched feeders of source.hpp
 
     std::pair<std::vector<float>, std::vector<Break>> psd(const MergeOpts &o = {}) const
     {

@@ -1,0 +1,166 @@
+// source.hpp -- header-only C++ mirror of the reference's file-backed `Source` (quartiq/stabilizer-stream
+// src/source.rs) over the C ABI, beside psd_cascade.hpp: same names, same granularity for get(), plus the batched
+// feed() a GPU path needs.  UDP, the noise generator and the DSM source are host I/O outside the accelerated path
+//  and are not mirrored.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/psdcascade.h"
+
+namespace stabilizer_stream {
+
+struct SourceOpts { // file-backed subset of SourceOpts (src/source.rs:15-48)
+    std::optional<std::string> file;        // --file: frames file
+    size_t frame_size = 8 + 30 * 2 * 6 * 4; // --frame-size default (src/source.rs:31)
+    bool repeat = false;                    // --repeat
+    std::optional<std::string> raw;         // --raw: single f32 trace, native endian
+};
+
+using Traces = std::vector<std::pair<const char *, std::vector<float>>>; // Vec<(&'static str, Vec<f32>)>
+
+// Frame::from_bytes + AdcDac::traces on the host (src/de/frame.rs:25-60, src/de/data.rs:11-82); throws the
+// de::Error texts (src/de/mod.rs:19-27).  Only get() uses it: bulk ingest decodes on the device.
+inline Traces decode_adcdac_frame(const uint8_t *buf, size_t len, uint32_t *seq_out, uint32_t *batches_out)
+{
+    if (len < 8)
+        throw std::runtime_error("frame shorter than its header"); // &input[..HEADER_SIZE] panics (frame.rs:50)
+    if (buf[0] != 0x7b || buf[1] != 0x05)
+        throw std::runtime_error("Invalid frame header");
+    if (buf[2] != 1)
+        throw std::runtime_error("Unknown format ID");
+    const uint32_t batches = buf[3];
+    if ((len - 8) % 64 != 0 || (len - 8) / 64 != batches)
+        throw std::runtime_error("Payload size");
+    *seq_out = (uint32_t)buf[4] | ((uint32_t)buf[5] << 8) | ((uint32_t)buf[6] << 16) | ((uint32_t)buf[7] << 24);
+    *batches_out = batches;
+    const float lsb = 4.096f * 2.5f / 32768.0f; // src/de/data.rs:28-35
+    static const char *names[4] = {"ADC0", "ADC1", "DAC0", "DAC1"};
+    Traces out;
+    for (int c = 0; c < 4; ++c) {
+        std::vector<float> v(8 * (size_t)batches);
+        for (uint32_t b = 0; b < batches; ++b)
+            for (int i = 0; i < 8; ++i) {
+                const uint8_t *p = buf + 8 + ((size_t)b * 4 + (size_t)c) * 16 + 2 * i; // [[[u8;2];8];4] per batch (data.rs:13)
+                uint16_t raw = (uint16_t)p[0] | ((uint16_t)p[1] << 8);
+                if (c >= 2)
+                    raw = (uint16_t)(raw + 0x8000u); // i16.wrapping_add(i16::MIN) (data.rs:64,75)
+                v[8 * (size_t)b + i] = (float)(int16_t)raw * lsb;
+            }
+        out.emplace_back(names[c], std::move(v));
+    }
+    return out;
+}
+
+class Source { // Source::new / get / finish (src/source.rs:66-171) for Data::File and Data::Raw
+public:
+    explicit Source(SourceOpts opts) : opts_(std::move(opts))
+    {
+        if (opts_.file.has_value() == opts_.raw.has_value())
+            throw std::invalid_argument("exactly one of file / raw (UDP, noise and dsm sources are out of scope)");
+        f_ = std::fopen((opts_.file ? *opts_.file : *opts_.raw).c_str(), "rb");
+        if (!f_)
+            throw std::runtime_error("cannot open the source file");
+    }
+    Source(const Source &) = delete;
+    Source &operator=(const Source &) = delete;
+    ~Source()
+    {
+        if (f_)
+            std::fclose(f_);
+    }
+
+    // One reference-sized chunk: Data::Raw at most 2048 bytes = 512 samples (src/source.rs:150-157), Data::File one
+    // frame (:135-147); --repeat wraps at the end of the file.  Returns false at EOF (the reference returns an Err).
+    bool get(Traces &out)
+    {
+        uint8_t buf[2048];
+        if (opts_.raw) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const size_t len = std::fread(buf, 1, sizeof buf, f_);
+                if (len == 0 && opts_.repeat && pass == 0) {
+                    std::fseek(f_, 0, SEEK_SET);
+                    continue;
+                }
+                if (len == 0)
+                    return false;
+                std::vector<float> v(len / 4); // cast_slice(&buf[..len / 4 * 4]) (:156)
+                std::memcpy(v.data(), buf, v.size() * 4);
+                out.clear();
+                out.emplace_back("raw", std::move(v));
+                return true;
+            }
+            return false;
+        }
+        if (opts_.frame_size > sizeof buf)
+            throw std::runtime_error("frame_size exceeds the 2048-byte buffer (src/source.rs:136)");
+        for (int pass = 0; pass < 2; ++pass) {
+            const size_t len = std::fread(buf, 1, opts_.frame_size, f_);
+            if (len < opts_.frame_size) { // read_exact: UnexpectedEof (:137-146)
+                if (opts_.repeat && pass == 0) {
+                    std::fseek(f_, 0, SEEK_SET);
+                    continue;
+                }
+                return false;
+            }
+            uint32_t seq = 0, batches = 0;
+            out = decode_adcdac_frame(buf, opts_.frame_size, &seq, &batches);
+            received_ += batches; // Loss::update (src/loss.rs:11-26)
+            if (have_seq_)
+                dropped_ += (uint32_t)(seq - next_seq_);
+            next_seq_ = seq + batches;
+            have_seq_ = true;
+            return true;
+        }
+        return false;
+    }
+
+    // Batched path: read up to max_bytes of the SAME byte formats and ingest them in one ABI call (raw -> channel
+    // `channel`, frames -> channels 0..3).  Returns the bytes consumed, 0 at EOF.
+    size_t feed(psdc_handle *h, size_t max_bytes = (size_t)64 << 20, uint32_t channel = 0)
+    {
+        const size_t unit = opts_.raw ? 4 : opts_.frame_size;
+        std::vector<uint8_t> buf(std::max<size_t>(1, max_bytes / unit) * unit);
+        for (int pass = 0; pass < 2; ++pass) {
+            const size_t len = std::fread(buf.data(), 1, buf.size(), f_) / unit * unit;
+            if (len == 0) {
+                if (opts_.repeat && pass == 0) {
+                    std::fseek(f_, 0, SEEK_SET);
+                    continue;
+                }
+                return 0;
+            }
+            int rc;
+            if (opts_.raw) {
+                rc = psdc_process(h, channel, reinterpret_cast<const float *>(buf.data()), len / 4);
+            } else {
+                size_t ok = 0;
+                rc = psdc_process_adcdac_frames(h, buf.data(), opts_.frame_size, len / opts_.frame_size, &ok);
+            }
+            if (rc < 0)
+                throw std::runtime_error(std::string("psdcascade: ") + psdc_last_error(h));
+            return len;
+        }
+        return 0;
+    }
+
+    // Loss::analyze (src/loss.rs:28-38): fraction of dropped batches on the get() path
+    double finish() const { return received_ ? (double)dropped_ / (double)(received_ + dropped_) : 0.0; }
+    uint64_t received() const { return received_; }
+    uint64_t dropped() const { return dropped_; }
+
+private:
+    SourceOpts opts_;
+    std::FILE *f_ = nullptr;
+    uint64_t received_ = 0, dropped_ = 0;
+    uint32_t next_seq_ = 0;
+    bool have_seq_ = false;
+};
+
+} // namespace stabilizer_stream

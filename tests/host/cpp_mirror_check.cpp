@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../stabilizer-stream_amd/cpp/psd_cascade.hpp"
+#include "../../stabilizer-stream_amd/cpp/source.hpp"
 
 using namespace stabilizer_stream;
 
@@ -86,6 +87,34 @@ int main()
             if (std::fabs(p * g * 0.5 - 1.0) > 10.0 / std::sqrt((double)s.count())) // :623-632
                 ++bad;
         std::printf("Psd<%zu>: %zu outputs, count %u, %zu pending\n", N, out.size(), s.count(), s.buf().size());
+    }
+    // the batched feeder (cpp/source.hpp): a raw f32 file as stream_to_raw writes it (src/bin/stream_to_raw.rs:24-25),
+    // ingested in 100 kB reads through Source::feed, must give the same PSD as process() on the same samples
+    {
+        std::vector<float> xs(total);
+        for (auto &v : xs)
+            v = (u(rng) - 0.5f) * std::sqrt(12.0f);
+        const std::string path = "/tmp/psd_cpp_mirror_raw.f32";
+        std::FILE *fp = std::fopen(path.c_str(), "wb");
+        std::fwrite(xs.data(), 4, xs.size(), fp);
+        std::fclose(fp);
+        SourceOpts so;
+        so.raw = path;
+        Source src(so);
+        PsdCascade<N> a, bref;
+        size_t fed = 0;
+        while (size_t nb = src.feed(a.handle(), 100000))
+            fed += nb;
+        bref.process(xs);
+        const auto [pa, ba] = a.psd(MergeOpts{});
+        const auto [pb, bb] = bref.psd(MergeOpts{});
+        if (fed != 4 * xs.size() || pa.size() != pb.size() || ba.size() != bb.size())
+            ++bad;
+        for (size_t k = 0; k < pa.size() && k < pb.size(); ++k)
+            if (std::fabs(pa[k] - pb[k]) > 4e-6f * pb[k])
+                ++bad;
+        std::remove(path.c_str());
+        std::printf("Source::feed: %zu bytes, %zu bins equal to process()\n", fed, pa.size());
     }
     bool threw = false;
     try {

@@ -1,0 +1,116 @@
+// source_check.cpp -- the C++ mirror of the reference's file-backed Source (cpp/source.hpp) at the reference's
+// granularity, on the CPU: Data::Raw hands out at most 512 samples per get() and wraps with --repeat
+// (src/source.rs:150-157); Data::File decodes one AdcDac frame per get() (src/source.rs:135-147,
+// src/de/data.rs:11-82) and counts sequence gaps (src/loss.rs:11-26).  usage: source_check <tmpdir>
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../stabilizer-stream_amd/cpp/source.hpp"
+
+using namespace stabilizer_stream;
+
+int main(int argc, char **argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    int bad = 0;
+    { // raw f32 file of 1300 samples: gets of 512, 512, 276, then EOF; with --repeat it wraps
+        std::vector<float> x(1300);
+        for (size_t i = 0; i < x.size(); ++i)
+            x[i] = 0.25f * (float)i - 7.0f;
+        const std::string path = dir + "/raw.f32";
+        std::FILE *f = std::fopen(path.c_str(), "wb");
+        std::fwrite(x.data(), 4, x.size(), f);
+        std::fclose(f);
+        SourceOpts o;
+        o.raw = path;
+        Source s(o);
+        Traces t;
+        size_t got = 0, calls = 0;
+        while (s.get(t)) {
+            if (t.size() != 1 || std::string(t[0].first) != "raw" || t[0].second.size() > 512)
+                ++bad;
+            for (float v : t[0].second)
+                if (v != x[got++])
+                    ++bad;
+            ++calls;
+        }
+        if (got != x.size() || calls != 3)
+            ++bad;
+        o.repeat = true;
+        Source r(o);
+        size_t n = 0;
+        for (int i = 0; i < 7; ++i) { // 3 gets per lap
+            if (!r.get(t))
+                ++bad;
+            n += t[0].second.size();
+        }
+        if (n != 2 * x.size() + 512)
+            ++bad;
+        std::printf("raw: %zu samples in %zu gets, %zu with --repeat\n", got, calls, n);
+    }
+    { // frames file: 5 frames of 3 batches, the fourth arrives 2 frames late (6 batches lost), seq wraps
+        const uint32_t batches = 3;
+        const size_t fs = 8 + 64 * batches;
+        const std::string path = dir + "/frames.bin";
+        std::FILE *f = std::fopen(path.c_str(), "wb");
+        uint32_t seq = 0xFFFFFFFAu;
+        for (int k = 0; k < 5; ++k) {
+            std::vector<uint8_t> fr(fs, 0);
+            fr[0] = 0x7b, fr[1] = 0x05, fr[2] = 1, fr[3] = (uint8_t)batches;
+            if (k == 3)
+                seq += 2 * batches;
+            for (int b = 0; b < 4; ++b)
+                fr[4 + b] = (uint8_t)(seq >> (8 * b));
+            seq += batches;
+            for (uint32_t b = 0; b < batches; ++b)
+                for (int c = 0; c < 4; ++c)
+                    for (int i = 0; i < 8; ++i) {
+                        const int16_t w = (int16_t)(1000 * k + 100 * (int)b + 10 * c + i - 2000);
+                        const uint16_t wire = c >= 2 ? (uint16_t)((uint16_t)w ^ 0x8000u) : (uint16_t)w; // DAC: offset binary
+                        uint8_t *p = fr.data() + 8 + ((size_t)b * 4 + c) * 16 + 2 * i;
+                        p[0] = (uint8_t)wire, p[1] = (uint8_t)(wire >> 8);
+                    }
+            std::fwrite(fr.data(), 1, fs, f);
+        }
+        std::fclose(f);
+        SourceOpts o;
+        o.file = path;
+        o.frame_size = fs;
+        Source s(o);
+        Traces t;
+        int k = 0;
+        const float lsb = 4.096f * 2.5f / 32768.0f;
+        while (s.get(t)) {
+            if (t.size() != 4 || std::string(t[2].first) != "DAC0")
+                ++bad;
+            for (int c = 0; c < 4; ++c)
+                for (uint32_t b = 0; b < batches; ++b)
+                    for (int i = 0; i < 8; ++i)
+                        if (t[c].second[8 * b + i] != (float)(1000 * k + 100 * (int)b + 10 * c + i - 2000) * lsb)
+                            ++bad;
+            ++k;
+        }
+        if (k != 5 || s.received() != 5 * batches || s.dropped() != 2 * batches ||
+            std::fabs(s.finish() - 6.0 / 21.0) > 1e-12)
+            ++bad;
+        std::printf("frames: %d frames, %llu batches received, %llu dropped, loss %.4f\n", k,
+                    (unsigned long long)s.received(), (unsigned long long)s.dropped(), s.finish());
+        // a corrupt header is the reference's de::Error::InvalidHeader
+        std::FILE *g = std::fopen(path.c_str(), "r+b");
+        std::fputc(0x00, g);
+        std::fclose(g);
+        Source c(o);
+        bool threw = false;
+        try {
+            c.get(t);
+        } catch (const std::runtime_error &e) {
+            threw = std::string(e.what()) == "Invalid frame header";
+        }
+        if (!threw)
+            ++bad;
+    }
+    std::printf(bad ? "FAIL\n" : "OK\n");
+    return bad ? 1 : 0;
+}

@@ -63,6 +63,17 @@ def test_host_programs(pkg):
     assert m.group(1) == m.group(2) and m.group(3) == m.group(4), line
 
 
+def test_cpp_source_mirror(pkg, tmp_path):
+    """cpp/source.hpp, the C++ mirror of the reference's file-backed Source (src/source.rs:135-157): get() at the
+    reference's granularity (512 raw samples / one frame per call, --repeat wrap), AdcDac decode on the host
+    (src/de/data.rs:11-82), Loss counting (src/loss.rs:11-26), de::Error text -- tests/host/source_check.cpp, CPU only."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.run(["make", "-C", host, "source_check"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(host, "source_check"), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert "3112 with --repeat" in r.stdout and "6 dropped" in r.stdout
+
+
 def test_cpp_mirror_builds_against_the_abi(pkg):
     """cpp/psd_cascade.hpp (the header-only C++ mirror of PsdCascade / Break / MergeOpts) compiles
     and links against include/psdcascade.h + libpsdcascade.so: tests/host/cpp_mirror_check.cpp is the
