@@ -333,6 +333,7 @@ def main():
                          # per one-span launch (--coalesce 1) and scaled by the spans per launch
                          "traffic": (tr["hbm_bytes_per_launch"] * prof["stage0_samples"] / max(1, prof["launches"]) / (T * C)
                                      if tr else None),
+                         "traffic_over_algorithmic": (tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]) if tr else None,
                          "traffic_source": (tr["round"] + " PMC passes (one-span launches), profiles/") if tr else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / max(1, prof["launches"]),
                          "spans_per_launch": prof["stage0_samples"] / max(1, prof["launches"]) / (T * C),
