@@ -255,10 +255,9 @@ def main():
     if args.warmup or dist is not None:
         # first-use costs of the read-out path belong to the warm-up: pinned read-out buffers, and for N > 1
         # the gather's point-to-point connections, which RCCL sets up on the first call that uses them
-        wspec, wmeta = shard.pack_readout(bank, C, n, torch)
+        wrec = shard.pack_readout(bank, C, n, pkg)
         if dist is not None:
-            shard.gather_readout(dist, wspec, wmeta,
-                                 device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+            shard.gather_readout(dist, wrec, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     barrier()
     prof0 = bank.profile_read()  # launches of the warm-up (kept: rocprofv3 --stats sees them too)
     t0 = time.perf_counter()
@@ -275,15 +274,14 @@ def main():
         t_drain = time.perf_counter() - t0
         bank.read_channel(0)  # debug only: the C-ABI part of the read-out alone
         t_rc = time.perf_counter() - t0
-    spec, meta = shard.pack_readout(bank, C, n, torch)
+    rec = shard.pack_readout(bank, C, n, pkg)
     if os.environ.get("PSD_BENCH_DEBUG"):
         t_pack = time.perf_counter() - t0
     if dist is not None:
-        specs, metas = shard.gather_readout(
-            dist, spec, meta, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+        recs = shard.gather_readout(dist, rec, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     else:
-        specs, metas = [spec], [meta]
-    merged = shard.stitch_gathered(pkg, n, specs, metas, [C] * world) if rank == 0 else None
+        recs = [rec]
+    merged = shard.stitch_gathered(pkg, recs, [C] * world) if rank == 0 else None
     if os.environ.get("PSD_BENCH_DEBUG"):
         t_read = time.perf_counter() - t0
     barrier()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PSDC_ABI_VERSION 2
+#define PSDC_ABI_VERSION 3
 
 /* status codes */
 #define PSDC_OK 0
@@ -47,6 +47,12 @@ extern "C" {
 /* Window<N> constructors (src/psd.rs:24-32, :42-55) */
 #define PSDC_WINDOW_RECTANGULAR 0
 #define PSDC_WINDOW_HANN 1
+#define PSDC_WINDOW_CUSTOM 2 /* a caller-built Window<N> (pub fields, src/psd.rs:12-20): psdc_create_window */
+
+/* `device` argument of the constructors: a HIP device index, or PSDC_DEVICE_DEFAULT = the index in the
+ * environment variable PSDC_DEVICE (0 when unset) -- what a shim whose constructor has no device argument
+ * (PsdCascade::<N>::default(), src/psd.rs:408) passes, so that one process per GPU selects its device from outside. */
+#define PSDC_DEVICE_DEFAULT (-1)
 
 /* Detrend (src/psd.rs:59-72) */
 #define PSDC_DETREND_NONE 0
@@ -114,6 +120,25 @@ typedef struct psdc_profile {
  * rectangular window and n < 256 take the generic two-pass kernels (welch +
  * hbf_dec8: same results, the stream is read twice, about a third of the rate). */
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
+
+/* The same with a caller-supplied `Window<N>` -- the struct is public with public fields `win`, `power`,
+ * `nenbw`, `overlap` (src/psd.rs:12-20) and `Psd::new(fft, win)` takes any (src/psd.rs:137) --: `win` holds n
+ * f32 weights (host memory, copied), `power` / `nenbw` feed gain() (src/psd.rs:279-283), `overlap` the segment
+ * hop.  The reference asserts (n - overlap) % 8 == 0 when the first segment is decimated (src/psd.rs:246-247);
+ * here that -- and overlap < n -- is checked at construction (PSDC_ERR_ARG through psdc_last_error(NULL)).
+ * A table that compares equal, bit for bit and in its three constants, to Window::hann() or
+ * Window::rectangular() is recognised as such (Hann keeps the single-pass fused kernels); any other table
+ * runs the generic two-pass kernels (same results, about a third of the rate). */
+psdc_handle *psdc_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap,
+                                uint32_t n_channels, int device);
+
+/* The Window of a handle as the library holds it: kind (PSDC_WINDOW_*), constants, and the n weights
+ * (win may be NULL).  What a gather of raw spectra needs beside them to run the stitch elsewhere. */
+int psdc_window_get(const psdc_handle *h, int *kind, float *power, float *nenbw, size_t *overlap, float *win);
+
+/* Window::hann() / Window::rectangular() (src/psd.rs:24-55) as the library builds them: n weights + constants
+ * (pure host; any n >= 2).  For callers that want to derive a table from them or compare. */
+int psdc_window_table(uint32_t n, int window_kind, float *win, float *power, float *nenbw, size_t *overlap);
 
 /* Drop (src/bin/psd.rs:190 `dec.clear()`). */
 void psdc_destroy(psdc_handle *h);
@@ -247,6 +272,11 @@ typedef struct psdc_stage psdc_stage;
 /* Psd::new(fft, win) (src/psd.rs:137-152): the FFT plan is the library's own (n as in psdc_create),
  * window_kind one of PSDC_WINDOW_*; detrend None, avg = u32::MAX, drain = hbf_dec_response_length(3). */
 psdc_stage *psdc_stage_create(uint32_t n, int window_kind, int device);
+/* Psd::new(fft, win) (src/psd.rs:137-152) with the caller's Window<N> (see psdc_create_window); the FFT plan
+ * argument of the reference has no counterpart: the library's own FFT of length n is used, and the shim keeps the
+ * reference's assert_eq!(N, fft.len()) (src/psd.rs:139) on its side. */
+psdc_stage *psdc_stage_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap,
+                                     int device);
 void psdc_stage_destroy(psdc_stage *s);
 psdc_stage *psdc_stage_clone(psdc_stage *s); /* #[derive(Clone)] src/psd.rs:122 */
 int psdc_stage_set_avg(psdc_stage *s, uint32_t avg);             /* Psd::set_avg      src/psd.rs:154-156 */
@@ -289,6 +319,41 @@ int psdc_stitch(uint32_t n, int window_kind, uint32_t n_stages, const uint32_t *
                 int keep_overlap, uint32_t min_count, int keep_transition_band, float *psd_out,
                 size_t psd_cap, size_t *psd_len, psdc_break *breaks, size_t breaks_cap,
                 size_t *n_breaks);
+
+/* The same stitch with the window given by its constants (any Window<N>) and the counts in 64 bits: a handle
+ * counts segments in 64 bits where the reference's u32 wraps (psdc_stage_stat.count saturates), and psd() divides
+ * by gain() of the 64-bit count; a gathered read-out must do the same to equal single-GPU psd() past 2^32
+ * segments.  `counts` (u32, as reported) fills Break.count / Break.processed. */
+int psdc_stitch_window(uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_stages,
+                       const uint64_t *counts64, const uint32_t *avgs, const uint64_t *pendings,
+                       const float *spectra, int keep_overlap, uint32_t min_count, int keep_transition_band,
+                       float *psd_out, size_t psd_cap, size_t *psd_len, psdc_break *breaks, size_t breaks_cap,
+                       size_t *n_breaks);
+
+/* ---- read-out for a gather (multi-GPU, src/bin/psd.rs:174-182 one cascade per trace) ------------------
+ * One trace per cascade shards by channel: every GPU (one process per GPU, or one process with one handle per
+ * device) runs whole cascades and nothing is exchanged during ingest.  At read-out every shard packs its raw
+ * accumulators and counters into a flat, fixed-size byte record -- psdc_readout_bytes(n, n_channels) bytes,
+ * the same on every shard with the same n and channel count, so one all-gather / gather of equal blocks over
+ * ANY transport (RCCL ncclAllGather on device copies, MPI, a socket, or plain memcpy between the handles of one
+ * process) collects them -- and the receiver stitches any channel of any record with psdc_unpack_stitch:
+ * bit-identical to psdc_psd on the shard itself (raw accumulators travel, normalisation happens after). */
+size_t psdc_readout_bytes(uint32_t n, uint32_t n_channels);
+/* flush + sync + copy: fills `buf` (cap >= psdc_readout_bytes(n, n_channels) of this handle) */
+int psdc_pack_readout(psdc_handle *h, void *buf, size_t cap, size_t *len);
+/* The same record built from stage data the caller holds (pure host): psdc_pack_init writes the header of an empty
+ * record of n_channels channels (no stages), psdc_pack_channel fills one channel (stage 0 first; spectra =
+ * n_stages rows of n/2+1 floats).  psdc_pack_readout is these two over a handle's own state. */
+int psdc_pack_init(void *buf, size_t cap, uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_channels);
+int psdc_pack_channel(void *buf, size_t len, uint32_t channel, uint32_t n_stages, const uint64_t *counts64,
+                      const uint32_t *avgs, const uint64_t *pendings, const float *spectra);
+/* record header: FFT size, channels in the record, stages of `channel` (pure host) */
+int psdc_unpack_info(const void *buf, size_t len, uint32_t channel, uint32_t *n, uint32_t *n_channels,
+                     uint32_t *n_stages);
+/* PsdCascade::psd (src/psd.rs:479-543) of one channel of a packed record (pure host; outputs as psdc_psd) */
+int psdc_unpack_stitch(const void *buf, size_t len, uint32_t channel, int keep_overlap, uint32_t min_count,
+                       int keep_transition_band, float *psd_out, size_t psd_cap, size_t *psd_len,
+                       psdc_break *breaks, size_t breaks_cap, size_t *n_breaks);
 
 /* Stream bookkeeping of src/psd.rs:196-269 in closed form: after `total`
  * samples have entered stage 0, how many stages exist and, per stage, samples

@@ -67,6 +67,8 @@ def _declare(L):
         f("ora_cascade_stage_buf", i32, [vp, i32, rp])
         f("ora_cascade_stage_gain", rt, [vp, i32])
         f("ora_cascade_psd", C.c_long, [vp, i32, u32, i32, rp, C.POINTER(Break)])
+        f("ora_cascade_new_window", vp, [i32, fp, C.c_float, C.c_float, i32])
+        f("ora_stage_new_window", vp, [i32, fp, C.c_float, C.c_float, i32])
         f("ora_stage_new", vp, [i32, i32])
         f("ora_stage_free", None, [vp])
         f("ora_stage_set", None, [vp, i32, u32])
@@ -107,10 +109,18 @@ class PsdCascade:
     """Oracle PsdCascade<N> (src/psd.rs:399-544). prec: 'f32' mirrors the reference, 'f64' truth."""
 
     def __init__(self, n, prec="f32", window="hann"):
+        """window: "hann" / "rect", or a caller-built Window<N> as (win[n] f32, power, nenbw, overlap)
+        (src/psd.rs:12-20: pub struct, pub fields)."""
         self.n, self.prec = n, prec
         self.np_t, self.c_t, self.sfx = _dt(prec)
         self.L = lib()
-        self.h = getattr(self.L, "ora_cascade_new" + self.sfx)(n, 1 if window == "hann" else 0)
+        if isinstance(window, str):
+            self.h = getattr(self.L, "ora_cascade_new" + self.sfx)(n, 1 if window == "hann" else 0)
+        else:
+            w, power, nenbw, overlap = window
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            assert w.size == n
+            self.h = getattr(self.L, "ora_cascade_new_window" + self.sfx)(n, _ptr(w, C.c_float), power, nenbw, overlap)
         if not self.h:
             raise ValueError("oracle: bad N")
 
@@ -186,7 +196,13 @@ class Psd:
         self.n = n
         self.np_t, self.c_t, self.sfx = _dt(prec)
         self.L = lib()
-        self.h = getattr(self.L, "ora_stage_new" + self.sfx)(n, 1 if window == "hann" else 0)
+        if isinstance(window, str):
+            self.h = getattr(self.L, "ora_stage_new" + self.sfx)(n, 1 if window == "hann" else 0)
+        else:  # Psd::new(fft, win) with a caller-built Window<N>: (win[n] f32, power, nenbw, overlap)
+            w, power, nenbw, overlap = window
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            assert w.size == n
+            self.h = getattr(self.L, "ora_stage_new_window" + self.sfx)(n, _ptr(w, C.c_float), power, nenbw, overlap)
         if not self.h:
             raise ValueError("oracle: bad N")
         getattr(self.L, "ora_stage_set" + self.sfx)(self.h, DETREND[detrend], avg)

@@ -53,6 +53,24 @@ static int SFX(window_init)(SFX(ora_window_t) * w, int n, int kind)
     return 0;
 }
 
+/* A caller-built Window<N> (pub struct, pub fields, src/psd.rs:12-20): the weights and constants are DEFINED by
+ * the caller in f32; the f64 instantiation only widens them. */
+static int SFX(window_init_table)(SFX(ora_window_t) * w, int n, const float *win, float power, float nenbw, int overlap)
+{
+    if (overlap < 0 || overlap >= n)
+        return -1;
+    w->n = n;
+    w->win = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+    if (!w->win)
+        return -1;
+    for (int i = 0; i < n; ++i)
+        w->win[i] = (REAL)win[i];
+    w->power = (REAL)power;
+    w->nenbw = (REAL)nenbw;
+    w->overlap = overlap;
+    return 0;
+}
+
 /* ---- FFT (src/psd.rs:213; rustfft 6.4.1 forward, unnormalised) ---------- */
 /* X[k] = sum_j c[j] exp(-2 pi i jk/N).  Iterative radix-2 DIT; any N = 2^m. */
 
@@ -445,6 +463,27 @@ SFX(ora_cascade) * SFX(ora_cascade_new)(int n, int window_kind)
     return c;
 }
 
+/* PsdCascade with a caller-built window: the reference's Default builds Hann (src/psd.rs:419); a cascade over
+ * another Window<N> is what `stages: Vec<Psd<N>>` + `win: Arc<Window<N>>` (:401-404) hold when constructed by hand */
+SFX(ora_cascade) * SFX(ora_cascade_new_window)(int n, const float *win, float power, float nenbw, int overlap)
+{
+    SFX(ora_cascade) *c = (SFX(ora_cascade) *)calloc(1, sizeof(*c));
+    if (!c)
+        return NULL;
+    c->n = n;
+    if (SFX(fft_init)(&c->fft, n) || SFX(window_init_table)(&c->win, n, win, power, nenbw, overlap)) {
+        free(c);
+        return NULL;
+    }
+    c->detrend = 0;
+    c->avg_limit = UINT32_MAX;
+    c->avg_count = UINT32_MAX;
+    c->a0 = (REAL *)calloc((size_t)n + (size_t)n / 8 + 8, sizeof(REAL));
+    c->a1 = (REAL *)calloc((size_t)n + (size_t)n / 8 + 8, sizeof(REAL));
+    c->xin = (REAL *)calloc((size_t)n * 8, sizeof(REAL));
+    return c;
+}
+
 void SFX(ora_cascade_free)(SFX(ora_cascade) * c)
 {
     if (!c)
@@ -630,6 +669,20 @@ SFX(ora_stage) * SFX(ora_stage_new)(int n, int window_kind)
     if (!s)
         return NULL;
     if (SFX(fft_init)(&s->fft, n) || SFX(window_init)(&s->win, n, window_kind) ||
+        SFX(psd_init)(&s->psd, &s->fft, &s->win)) {
+        free(s);
+        return NULL;
+    }
+    return s;
+}
+
+/* Psd::new(fft, win) with a caller-built Window<N> (src/psd.rs:137-152) */
+SFX(ora_stage) * SFX(ora_stage_new_window)(int n, const float *win, float power, float nenbw, int overlap)
+{
+    SFX(ora_stage) *s = (SFX(ora_stage) *)calloc(1, sizeof(*s));
+    if (!s)
+        return NULL;
+    if (SFX(fft_init)(&s->fft, n) || SFX(window_init_table)(&s->win, n, win, power, nenbw, overlap) ||
         SFX(psd_init)(&s->psd, &s->fft, &s->win)) {
         free(s);
         return NULL;

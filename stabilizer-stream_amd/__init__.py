@@ -26,7 +26,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsdcascade.so")
+# $PSDC_LIB: another build of the SAME library (tools/gpu.sh variants: timing-only ablation builds) -- never a fallback
+LIB_PATH = os.environ.get("PSDC_LIB") or os.path.join(_HERE, "libpsdcascade.so")
 U32_MAX = 0xFFFFFFFF
 
 PSDC_OK = 0
@@ -57,9 +58,44 @@ class Detrend(enum.IntEnum):
 
 
 class Window(enum.IntEnum):
-    """Window::rectangular / Window::hann (src/psd.rs:24-55)"""
+    """Window::rectangular / Window::hann (src/psd.rs:24-55) by kind"""
     RECTANGULAR = 0
     HANN = 1
+    CUSTOM = 2
+
+
+@dataclass(frozen=True, eq=False)
+class WindowTable:
+    """`Window<N>` (src/psd.rs:12-20): a public struct with public fields, so a caller may build any.
+
+        WindowTable.hann(n) / .rectangular(n)        Window::hann() / Window::rectangular()   src/psd.rs:24-55
+        WindowTable(win, power, nenbw, overlap)      Window { win, power, nenbw, overlap }
+    """
+    win: np.ndarray  # [n] f32
+    power: float     # src/psd.rs:15
+    nenbw: float     # src/psd.rs:17
+    overlap: int     # src/psd.rs:19
+
+    @staticmethod
+    def _kind(n, kind):
+        w = np.empty(n, dtype=np.float32)
+        p, e, ov = C.c_float(), C.c_float(), C.c_size_t()
+        rc = lib().psdc_window_table(n, int(kind), _fptr(w), C.byref(p), C.byref(e), C.byref(ov))
+        if rc < 0:
+            _raise(rc)
+        return WindowTable(w, p.value, e.value, ov.value)
+
+    @staticmethod
+    def hann(n):
+        return WindowTable._kind(n, Window.HANN)
+
+    @staticmethod
+    def rectangular(n):
+        return WindowTable._kind(n, Window.RECTANGULAR)
+
+    def as_tuple(self):
+        """(win, power, nenbw, overlap)"""
+        return (self.win, self.power, self.nenbw, self.overlap)
 
 
 @dataclass(frozen=True)
@@ -190,6 +226,19 @@ def lib():
     f("psdc_abi_version", i32, [])
     f("psdc_last_error", C.c_char_p, [H])
     f("psdc_create", H, [u32, i32, u32, i32])
+    f("psdc_create_window", H, [u32, fp, C.c_float, C.c_float, sz, u32, i32])
+    f("psdc_window_get", i32, [H, C.POINTER(i32), fp, fp, C.POINTER(sz), fp])
+    f("psdc_window_table", i32, [u32, i32, fp, fp, fp, C.POINTER(sz)])
+    f("psdc_stage_create_window", H, [u32, fp, C.c_float, C.c_float, sz, i32])
+    f("psdc_stitch_window", i32, [u32, C.c_float, C.c_float, sz, u32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), fp,
+                                  i32, u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz, C.POINTER(sz)])
+    f("psdc_readout_bytes", sz, [u32, u32])
+    f("psdc_pack_readout", i32, [H, C.c_void_p, sz, C.POINTER(sz)])
+    f("psdc_pack_init", i32, [C.c_void_p, sz, u32, C.c_float, C.c_float, sz, u32])
+    f("psdc_pack_channel", i32, [C.c_void_p, sz, u32, u32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), fp])
+    f("psdc_unpack_info", i32, [C.c_void_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)])
+    f("psdc_unpack_stitch", i32, [C.c_void_p, sz, u32, i32, u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz,
+                                  C.POINTER(sz)])
     f("psdc_destroy", None, [H])
     f("psdc_clone", H, [H])
     f("psdc_reset", i32, [H])
@@ -252,6 +301,9 @@ EXPORTS = [
     "psdc_stage_create", "psdc_stage_destroy", "psdc_stage_clone", "psdc_stage_set_avg", "psdc_stage_set_detrend",
     "psdc_stage_process", "psdc_stage_process_device", "psdc_stage_get_spectrum", "psdc_stage_get_count",
     "psdc_stage_get_gain", "psdc_stage_get_buf", "psdc_stage_last_error",
+    "psdc_create_window", "psdc_window_get", "psdc_window_table", "psdc_stage_create_window", "psdc_stitch_window",
+    "psdc_readout_bytes", "psdc_pack_readout", "psdc_unpack_info", "psdc_unpack_stitch",
+    "psdc_pack_init", "psdc_pack_channel",
 ]
 
 
@@ -270,11 +322,37 @@ class PsdCascadeBank:
     """`n_channels` independent PsdCascade<N> batched on one GPU (one handle of the C ABI)."""
 
     def __init__(self, n, n_channels=1, window=Window.HANN, device=0, _handle=None):
-        self.n, self.n_channels, self.window, self.device = n, n_channels, Window(window), device
+        """window: a Window kind, or a caller-built WindowTable (any Window<N>, src/psd.rs:12-20).
+        device: HIP device index, or -1 = the index in $PSDC_DEVICE (0 when unset)."""
+        self.n, self.n_channels, self.window, self.device = n, n_channels, window, device
         self._L = lib()
-        self._h = _handle if _handle is not None else self._L.psdc_create(n, int(window), n_channels, device)
+        if _handle is not None:
+            self._h = _handle
+        elif isinstance(window, WindowTable):
+            w = np.ascontiguousarray(window.win, dtype=np.float32)
+            if w.size != n:
+                raise PsdError(ERR_ARG, "window table length != n")
+            self._h = self._L.psdc_create_window(n, _fptr(w), window.power, window.nenbw, window.overlap, n_channels, device)
+        else:
+            self._h = self._L.psdc_create(n, int(window), n_channels, device)
         if not self._h:
             _raise(ERR_DEVICE)
+
+    def window_get(self):
+        """(kind, WindowTable) as the library holds it: a table equal to Window::hann() is recognised as HANN."""
+        k, p, e, ov = C.c_int(), C.c_float(), C.c_float(), C.c_size_t()
+        w = np.empty(self.n, dtype=np.float32)
+        self._ck(self._L.psdc_window_get(self._h, C.byref(k), C.byref(p), C.byref(e), C.byref(ov), _fptr(w)))
+        return Window(k.value), WindowTable(w, p.value, e.value, ov.value)
+
+    def pack_readout(self):
+        """psdc_pack_readout: the fixed-size byte record of this handle's raw accumulators and counters."""
+        need = self._L.psdc_readout_bytes(self.n, self.n_channels)
+        buf = np.empty(need, dtype=np.uint8)
+        ln = C.c_size_t()
+        self._ck(self._L.psdc_pack_readout(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(ln)))
+        assert ln.value == need
+        return buf
 
     def close(self):
         if getattr(self, "_h", None):
@@ -483,11 +561,28 @@ class Psd:
     """
 
     def __init__(self, n, window=Window.HANN, device=0, _handle=None):
-        self.n, self.window, self.device = n, Window(window), device
+        self.n, self.window, self.device = n, window, device
         self._L = lib()
-        self._s = _handle if _handle is not None else self._L.psdc_stage_create(n, int(window), device)
+        if _handle is not None:
+            self._s = _handle
+        elif isinstance(window, WindowTable):
+            w = np.ascontiguousarray(window.win, dtype=np.float32)
+            if w.size != n:
+                raise PsdError(ERR_ARG, "window table length != n")
+            self._s = self._L.psdc_stage_create_window(n, _fptr(w), window.power, window.nenbw, window.overlap, device)
+        else:
+            self._s = self._L.psdc_stage_create(n, int(window), device)
         if not self._s:
             _raise(ERR_DEVICE)
+
+    @staticmethod
+    def new(fft_len, win, n=None, device=0):
+        """`Psd::<N>::new(fft, win)` (src/psd.rs:137-152): `fft_len` stands for the plan (`fft.len()`), `win` is a
+        WindowTable; assert_eq!(N, fft.len()) (src/psd.rs:139) is kept."""
+        n = len(win.win) if n is None else n
+        if fft_len != n:
+            raise PsdError(ERR_ARG, f"assertion failed: N == fft.len() ({n} vs {fft_len}) (src/psd.rs:139)")
+        return Psd(n, win, device)
 
     def close(self):
         if getattr(self, "_s", None):
@@ -573,9 +668,25 @@ def plan_counts(n, total, window=Window.HANN, cap=32):
 
 
 def stitch(n, counts, avgs, pendings, spectra, opts=MergeOpts(), window=Window.HANN):
-    """PsdCascade::psd (src/psd.rs:479-543) on gathered per-stage data (stage 0 first)."""
+    """PsdCascade::psd (src/psd.rs:479-543) on gathered per-stage data (stage 0 first).  `counts` may exceed
+    u32 (the library counts in 64 bits); `window` is a kind or a WindowTable."""
     L = lib()
     ns = len(counts)
+    if isinstance(window, WindowTable) or any(int(c) > U32_MAX for c in counts):
+        wt = window if isinstance(window, WindowTable) else WindowTable._kind(n, window)
+        c64 = (C.c_uint64 * max(1, ns))(*[int(c) for c in counts])
+        aa = (C.c_uint32 * max(1, ns))(*avgs)
+        pp = (C.c_uint64 * max(1, ns))(*pendings)
+        sp = np.ascontiguousarray(spectra, dtype=np.float32).reshape(ns, n // 2 + 1) if ns else np.zeros((1, 1), np.float32)
+        out = np.empty(max(1, ns * (n // 2 + 1)), dtype=np.float32)
+        br = (_CBreak * max(1, ns))()
+        plen, nb = C.c_size_t(), C.c_size_t()
+        rc = L.psdc_stitch_window(n, wt.power, wt.nenbw, wt.overlap, ns, c64, aa, pp, _fptr(sp), int(opts.keep_overlap),
+                                  opts.min_count, int(opts.keep_transition_band), _fptr(out), out.size, C.byref(plen), br,
+                                  ns, C.byref(nb))
+        if rc < 0:
+            _raise(rc)
+        return out[:plen.value].copy(), [Break._from_c(br[i]) for i in range(nb.value)]
     cc = (C.c_uint32 * max(1, ns))(*counts)
     aa = (C.c_uint32 * max(1, ns))(*avgs)
     pp = (C.c_uint64 * max(1, ns))(*pendings)
@@ -586,6 +697,56 @@ def stitch(n, counts, avgs, pendings, spectra, opts=MergeOpts(), window=Window.H
     rc = L.psdc_stitch(n, int(window), ns, cc, aa, pp, _fptr(sp), int(opts.keep_overlap),
                        opts.min_count, int(opts.keep_transition_band), _fptr(out), out.size,
                        C.byref(plen), br, ns, C.byref(nb))
+    if rc < 0:
+        _raise(rc)
+    return out[:plen.value].copy(), [Break._from_c(br[i]) for i in range(nb.value)]
+
+
+def readout_bytes(n, n_channels):
+    return lib().psdc_readout_bytes(n, n_channels)
+
+
+def pack_record(n, channels, window=Window.HANN, rows=None):
+    """A packed read-out record (psdc_pack_init / psdc_pack_channel, pure host) from stage data held by the caller:
+    channels = [(counts, avgs, pendings, spectra[ns, n/2+1]) ...]; `rows` >= len(channels) pads with empty channels."""
+    L = lib()
+    wt = window if isinstance(window, WindowTable) else WindowTable._kind(n, window)
+    rows = max(rows or 0, len(channels))
+    buf = np.empty(L.psdc_readout_bytes(n, rows), dtype=np.uint8)
+    rc = L.psdc_pack_init(buf.ctypes.data_as(C.c_void_p), buf.size, n, wt.power, wt.nenbw, wt.overlap, rows)
+    if rc < 0:
+        _raise(rc)
+    for c, (counts, avgs, pend, sp) in enumerate(channels):
+        ns = len(counts)
+        sp = np.ascontiguousarray(sp, dtype=np.float32).reshape(ns, n // 2 + 1) if ns else np.zeros((1, 1), np.float32)
+        rc = L.psdc_pack_channel(buf.ctypes.data_as(C.c_void_p), buf.size, c, ns,
+                                 (C.c_uint64 * max(1, ns))(*[int(v) for v in counts]),
+                                 (C.c_uint32 * max(1, ns))(*[int(v) for v in avgs]),
+                                 (C.c_uint64 * max(1, ns))(*[int(v) for v in pend]), _fptr(sp))
+        if rc < 0:
+            _raise(rc)
+    return buf
+
+
+def unpack_info(buf, channel=0):
+    """(n, n_channels, n_stages of `channel`) of a packed read-out record (bytes-like / uint8 array)."""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    n, nc, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib().psdc_unpack_info(b.ctypes.data_as(C.c_void_p), b.size, channel, C.byref(n), C.byref(nc), C.byref(ns))
+    if rc < 0:
+        _raise(rc)
+    return n.value, nc.value, ns.value
+
+
+def unpack_stitch(buf, channel=0, opts=MergeOpts()):
+    """PsdCascade::psd of one channel of a packed read-out record: identical to psd() on the handle that packed it."""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    n, _, ns = unpack_info(b, channel)
+    out = np.empty(max(1, ns * (n // 2 + 1)), dtype=np.float32)
+    br = (_CBreak * max(1, ns))()
+    plen, nb = C.c_size_t(), C.c_size_t()
+    rc = lib().psdc_unpack_stitch(b.ctypes.data_as(C.c_void_p), b.size, channel, int(opts.keep_overlap), opts.min_count,
+                                  int(opts.keep_transition_band), _fptr(out), out.size, C.byref(plen), br, ns, C.byref(nb))
     if rc < 0:
         _raise(rc)
     return out[:plen.value].copy(), [Break._from_c(br[i]) for i in range(nb.value)]

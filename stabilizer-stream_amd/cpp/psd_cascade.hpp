@@ -53,17 +53,44 @@ struct Break { // src/psd.rs:290-337
     }
 };
 
-enum class Window : int { Rectangular = 0, Hann = 1 }; // Window::rectangular / Window::hann (src/psd.rs:24-55)
+// Window<N> (src/psd.rs:12-56): a plain struct with public fields, so a caller may build any
+template <size_t N>
+struct Window {
+    std::vector<float> win; // [f32; N]
+    float power = 1.0f;     // src/psd.rs:15
+    float nenbw = 1.0f;     // src/psd.rs:17
+    size_t overlap = 0;     // src/psd.rs:19
+
+    static Window rectangular() { return from_kind(PSDC_WINDOW_RECTANGULAR); } // src/psd.rs:24-32
+    static Window hann() { return from_kind(PSDC_WINDOW_HANN); }               // src/psd.rs:42-55
+
+private:
+    static Window from_kind(int kind)
+    {
+        Window w;
+        w.win.resize(N);
+        if (psdc_window_table(N, kind, w.win.data(), &w.power, &w.nenbw, &w.overlap) < 0)
+            throw std::runtime_error(psdc_last_error(nullptr));
+        return w;
+    }
+};
 
 // Psd<N> with the PsdStage trait (src/psd.rs:122-288): one stage, the decimated stream handed back.
 template <size_t N>
 class Psd {
 public:
-    explicit Psd(Window w = Window::Hann, int device = 0) : s_(psdc_stage_create(N, static_cast<int>(w), device))
+    // Psd::new(fft, win) (src/psd.rs:137-152): `fft_len` stands for the plan's fft.len() (the transform is the
+    // library's own), `win` is any Window<N>; device -1 = $PSDC_DEVICE
+    Psd(size_t fft_len, const Window<N> &win, int device = PSDC_DEVICE_DEFAULT)
     {
+        static_assert(N >= 2, "Nyquist and DC distinction (src/psd.rs:138)");
+        if (fft_len != N || win.win.size() != N)
+            throw std::invalid_argument("assertion failed: N == fft.len() (src/psd.rs:139)");
+        s_ = psdc_stage_create_window(N, win.win.data(), win.power, win.nenbw, win.overlap, device);
         if (!s_)
             throw std::runtime_error(psdc_last_error(nullptr));
     }
+    Psd() : Psd(N, Window<N>::hann()) {}
     Psd(const Psd &o) : s_(psdc_stage_clone(o.s_))
     {
         if (!s_)
@@ -155,10 +182,18 @@ inline std::pair<float, std::vector<std::pair<double, double>>> trace_plot(std::
 template <size_t N>
 class PsdCascade { // src/psd.rs:399-544
 public:
-    explicit PsdCascade(int device = 0) : h_(psdc_create(N, PSDC_WINDOW_HANN, 1, device))
+    // PsdCascade::<N>::default() (src/psd.rs:408-423); device -1 = $PSDC_DEVICE
+    explicit PsdCascade(int device = PSDC_DEVICE_DEFAULT) : h_(psdc_create(N, PSDC_WINDOW_HANN, 1, device))
     {
         if (!h_)
             throw std::runtime_error(psdc_last_error(nullptr));
+    }
+    // a cascade over a caller-built window (the reference's Default always plans Hann)
+    explicit PsdCascade(const Window<N> &win, int device = PSDC_DEVICE_DEFAULT)
+        : h_(win.win.size() == N ? psdc_create_window(N, win.win.data(), win.power, win.nenbw, win.overlap, 1, device) : nullptr)
+    {
+        if (!h_)
+            throw std::runtime_error(win.win.size() == N ? psdc_last_error(nullptr) : "window table length != N");
     }
     PsdCascade(const PsdCascade &o) : h_(psdc_clone(o.h_))
     {
@@ -179,6 +214,14 @@ public:
     void process(std::span<const float> x) { check(psdc_process(h_, 0, x.data(), x.size())); }
     void process_device(const float *d_x, size_t len) { check(psdc_process_device(h_, 0, d_x, len)); }
     psdc_handle *handle() const { return h_; } // for the batched feeders of source.hpp
+    // the multi-GPU read-out record (psdc_pack_readout): gather with any transport, stitch with psd_from_readout
+    std::vector<unsigned char> pack_readout() const
+    {
+        std::vector<unsigned char> rec(psdc_readout_bytes(N, 1));
+        size_t len = 0;
+        check(psdc_pack_readout(h_, rec.data(), rec.size(), &len));
+        return rec;
+    }
 
     std::pair<std::vector<float>, std::vector<Break>> psd(const MergeOpts &o = {}) const
     {
@@ -207,5 +250,28 @@ private:
     }
     psdc_handle *h_;
 };
+
+// PsdCascade::psd (src/psd.rs:479-543) of channel `channel` of a gathered read-out record
+inline std::pair<std::vector<float>, std::vector<Break>> psd_from_readout(std::span<const unsigned char> rec, uint32_t channel = 0,
+                                                                          const MergeOpts &o = {})
+{
+    uint32_t n = 0, nc = 0, ns = 0;
+    if (psdc_unpack_info(rec.data(), rec.size(), channel, &n, &nc, &ns) < 0)
+        throw std::runtime_error(psdc_last_error(nullptr));
+    std::vector<float> p(static_cast<size_t>(ns) * (n / 2 + 1));
+    std::vector<psdc_break> b(ns);
+    size_t plen = 0, nb = 0;
+    if (psdc_unpack_stitch(rec.data(), rec.size(), channel, o.keep_overlap, o.min_count, o.keep_transition_band, p.data(),
+                           p.size(), &plen, b.data(), b.size(), &nb) < 0)
+        throw std::runtime_error(psdc_last_error(nullptr));
+    p.resize(plen);
+    std::vector<Break> out;
+    for (size_t i = 0; i < nb; ++i)
+        out.push_back(Break{static_cast<size_t>(b[i].start), b[i].include != 0, b[i].count, b[i].avg,
+                            {b[i].bins_start, b[i].bins_end}, static_cast<size_t>(b[i].fft_size),
+                            static_cast<size_t>(b[i].decimation), static_cast<size_t>(b[i].pending),
+                            static_cast<size_t>(b[i].processed)});
+    return {std::move(p), std::move(out)};
+}
 
 } // namespace stabilizer_stream

@@ -77,26 +77,26 @@ public:
     }
 
     // One reference-sized chunk: Data::Raw at most 2048 bytes = 512 samples (src/source.rs:150-157), Data::File one
-    // frame (:135-147); --repeat wraps at the end of the file.  Returns false at EOF (the reference returns an Err).
+    // frame (:135-147); --repeat wraps at the end of the file.  End of file without --repeat, as in the reference:
+    // Data::Raw keeps returning Ok with an EMPTY "raw" trace (`read` gives 0 bytes, :151-157 -- also for a tail
+    // shorter than one f32); Data::File fails (`read_exact` -> UnexpectedEof, :137-146): get() returns false.
+    // at_eof() tells a raw reader that the file is exhausted.
+    bool at_eof() const { return eof_; }
     bool get(Traces &out)
     {
         uint8_t buf[2048];
         if (opts_.raw) {
-            for (int pass = 0; pass < 2; ++pass) {
-                const size_t len = std::fread(buf, 1, sizeof buf, f_);
-                if (len == 0 && opts_.repeat && pass == 0) {
-                    std::fseek(f_, 0, SEEK_SET);
-                    continue;
-                }
-                if (len == 0)
-                    return false;
-                std::vector<float> v(len / 4); // cast_slice(&buf[..len / 4 * 4]) (:156)
-                std::memcpy(v.data(), buf, v.size() * 4);
-                out.clear();
-                out.emplace_back("raw", std::move(v));
-                return true;
+            size_t len = std::fread(buf, 1, sizeof buf, f_);
+            if (len == 0 && opts_.repeat) { // :152-155 (the reference spins on an empty file; one retry here)
+                std::fseek(f_, 0, SEEK_SET);
+                len = std::fread(buf, 1, sizeof buf, f_);
             }
-            return false;
+            eof_ = len == 0;
+            std::vector<float> v(len / 4); // cast_slice(&buf[..len / 4 * 4]) (:156)
+            std::memcpy(v.data(), buf, v.size() * 4);
+            out.clear();
+            out.emplace_back("raw", std::move(v));
+            return true;
         }
         if (opts_.frame_size > sizeof buf)
             throw std::runtime_error("frame_size exceeds the 2048-byte buffer (src/source.rs:136)");
@@ -161,6 +161,7 @@ private:
     uint64_t received_ = 0, dropped_ = 0;
     uint32_t next_seq_ = 0;
     bool have_seq_ = false;
+    bool eof_ = false;
 };
 
 } // namespace stabilizer_stream

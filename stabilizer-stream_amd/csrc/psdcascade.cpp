@@ -90,6 +90,7 @@ struct psdc_handle {
     int window_kind = PSDC_WINDOW_HANN;
     Geometry geo;
     float nenbw = 1.5f, power = 0.25f;
+    std::vector<float> win_host; // the Window's weights as uploaded (psdc_window_get, psdc_clone, pack_readout)
     uint32_t n_channels = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -328,6 +329,50 @@ bool window_consts(uint32_t n, int kind, WindowConsts *w)
     return false;
 }
 
+// the weights of Window::hann() / Window::rectangular() exactly as the reference builds them (src/psd.rs:24-32, :42-55)
+void window_weights(uint32_t n, int kind, float *win)
+{
+    if (kind == PSDC_WINDOW_HANN) {
+        const float df = 3.14159265358979323846f / (float)n; // core::f32::consts::PI / N as f32  :44
+        for (uint32_t i = 0; i < n; ++i) {
+            const float s = sinf(df * (float)i); // (df * i as f32).sin().powi(2)  :47
+            win[i] = s * s;
+        }
+    } else {
+        for (uint32_t i = 0; i < n; ++i)
+            win[i] = 1.0f;
+    }
+}
+
+// a caller-built Window<N>: which of the library's kinds is it?
+int classify_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap)
+{
+    for (int kind : {PSDC_WINDOW_HANN, PSDC_WINDOW_RECTANGULAR}) {
+        WindowConsts wc{};
+        window_consts(n, kind, &wc);
+        if (wc.power != power || wc.nenbw != nenbw || (size_t)wc.overlap != overlap)
+            continue;
+        std::vector<float> ref(n);
+        window_weights(n, kind, ref.data());
+        if (memcmp(ref.data(), win, sizeof(float) * n) == 0)
+            return kind;
+    }
+    return PSDC_WINDOW_CUSTOM;
+}
+
+// PSDC_DEVICE_DEFAULT -> the index in $PSDC_DEVICE (0 when unset or unparsable)
+int resolve_device(int device)
+{
+    if (device != PSDC_DEVICE_DEFAULT)
+        return device;
+    const char *e = getenv("PSDC_DEVICE");
+    if (!e || !*e)
+        return 0;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end && *end == 0 && v >= 0 && v < 1024) ? (int)v : -2; // -2: rejected as out of range below
+}
+
 bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1)) == 0; }
 
 // PsdStage::gain (src/psd.rs:279-283): (N/2 * count) as f32, then two f32 multiplies.  The
@@ -481,7 +526,8 @@ int ensure_room(psdc_handle *h, StageState &s, uint64_t new_end)
 }
 
 // both ping-pong buffers can hold `need` floats (content of the current one is kept); when they have
-// to grow they grow to `grow_to` (>= need) at once -- a re-allocation synchronises the stream
+// to grow they grow to `grow_to` (>= need) at once -- growing never waits for the device: the buffers it replaces
+// are retired and released at the next sync or read-out (release_retired)
 int ensure_cap(psdc_handle *h, StageState &s, size_t need, size_t grow_to = 0)
 {
     if (need <= s.buf.cap)
@@ -1159,9 +1205,11 @@ int flush_all(psdc_handle *h)
 // the stream is idle: nothing can still read the buffers that growth replaced
 int release_retired(psdc_handle *h)
 {
-    for (float *p : h->retired)
+    while (!h->retired.empty()) { // popped before it is freed: a failing hipFree never leaves a freed pointer listed
+        float *p = h->retired.back();
+        h->retired.pop_back();
         HIPCHK(h, hipFree(p));
-    h->retired.clear();
+    }
     return PSDC_OK;
 }
 
@@ -1287,19 +1335,26 @@ struct PsdkSegvInstall {
 } g_psdk_segv_install;
 #endif
 
-psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device)
+} // extern "C"
+
+namespace {
+
+// every constructor ends here: window_kind HANN / RECTANGULAR (win == nullptr: the library's table) or CUSTOM
+// (win = the caller's n weights, wc = its constants)
+psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, WindowConsts wc, uint32_t n_channels,
+                         int device)
 {
-    WindowConsts wc{};
+    device = resolve_device(device);
     if (!valid_n(n) || !welch_supported((int)n)) {
         fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 16384]");
         return nullptr;
     }
-    if (!window_consts(n, window_kind, &wc)) {
+    if (window_kind != PSDC_WINDOW_CUSTOM && !window_consts(n, window_kind, &wc)) {
         fail(nullptr, PSDC_ERR_ARG, "psdc_create: unknown window kind");
         return nullptr;
     }
-    if ((n - wc.overlap) % 8 != 0) { // src/psd.rs:246-247
-        fail(nullptr, PSDC_ERR_ARG, "psdc_create: (n - overlap) must be a multiple of 8");
+    if (wc.overlap >= n || (n - wc.overlap) % 8 != 0) { // src/psd.rs:246-247 (overlap >= n: `N - overlap` underflows / no progress)
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: overlap must be below n and (n - overlap) a multiple of 8 (src/psd.rs:247)");
         return nullptr;
     }
     if (n_channels == 0 || n_channels > 4096) {
@@ -1336,18 +1391,13 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
     h->ch.resize(n_channels);
     h->min_pairs = fused_supported((int)n) ? 32u * (uint32_t)std::max(1, fused_pairs_per_block((int)n, 1)) : 0u;
 
-    // window table exactly as the reference builds it (src/psd.rs:44-48), twiddles in f64
+    // window table exactly as the reference builds it (src/psd.rs:44-48) or as the caller did, twiddles in f64
     std::vector<float> win(n);
-    if (window_kind == PSDC_WINDOW_HANN) {
-        const float df = 3.14159265358979323846f / (float)n;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float s = sinf(df * (float)i);
-            win[i] = s * s;
-        }
-    } else {
-        for (uint32_t i = 0; i < n; ++i)
-            win[i] = 1.0f;
-    }
+    if (window_kind == PSDC_WINDOW_CUSTOM)
+        memcpy(win.data(), win_in, sizeof(float) * n);
+    else
+        window_weights(n, window_kind, win.data());
+    h->win_host = win;
     std::vector<cf> tw(n);
     for (uint32_t i = 0; i < n; ++i) {
         const double a = -2.0 * M_PI * (double)i / (double)n;
@@ -1405,6 +1455,80 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
     if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(tw)");
     return h;
+}
+
+// a caller's Window<N> -> (kind, constants) or an error message
+const char *check_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap, int *kind, WindowConsts *wc)
+{
+    if (!valid_n(n))
+        return "n must be a power of two in [16, 16384]";
+    if (!win)
+        return "null window";
+    if (overlap >= n || (n - overlap) % 8 != 0)
+        return "overlap must be below n and (n - overlap) a multiple of 8 (src/psd.rs:247)";
+    if (!std::isfinite(power) || !std::isfinite(nenbw))
+        return "window power / nenbw not finite";
+    *kind = classify_window(n, win, power, nenbw, overlap);
+    *wc = {nenbw, power, (uint32_t)overlap};
+    return nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device)
+{
+    if (window_kind != PSDC_WINDOW_HANN && window_kind != PSDC_WINDOW_RECTANGULAR) {
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: unknown window kind (a caller-built Window goes through psdc_create_window)");
+        return nullptr;
+    }
+    return create_impl(n, window_kind, nullptr, WindowConsts{}, n_channels, device);
+}
+
+psdc_handle *psdc_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap,
+                                uint32_t n_channels, int device)
+{
+    int kind = 0;
+    WindowConsts wc{};
+    if (const char *msg = check_window(n, win, power, nenbw, overlap, &kind, &wc)) {
+        fail(nullptr, PSDC_ERR_ARG, std::string("psdc_create_window: ") + msg);
+        return nullptr;
+    }
+    return create_impl(n, kind, kind == PSDC_WINDOW_CUSTOM ? win : nullptr, wc, n_channels, device);
+}
+
+int psdc_window_get(const psdc_handle *h, int *kind, float *power, float *nenbw, size_t *overlap, float *win)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    if (kind)
+        *kind = h->window_kind;
+    if (power)
+        *power = h->power;
+    if (nenbw)
+        *nenbw = h->nenbw;
+    if (overlap)
+        *overlap = h->geo.overlap;
+    if (win)
+        memcpy(win, h->win_host.data(), sizeof(float) * h->n);
+    return PSDC_OK;
+}
+
+int psdc_window_table(uint32_t n, int window_kind, float *win, float *power, float *nenbw, size_t *overlap)
+{
+    WindowConsts wc{};
+    if (n < 2 || !window_consts(n, window_kind, &wc))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_window_table: bad arguments");
+    if (win)
+        window_weights(n, window_kind, win);
+    if (power)
+        *power = wc.power;
+    if (nenbw)
+        *nenbw = wc.nenbw;
+    if (overlap)
+        *overlap = wc.overlap;
+    return PSDC_OK;
 }
 
 void psdc_destroy(psdc_handle *h)
@@ -2185,7 +2309,8 @@ psdc_handle *psdc_clone(psdc_handle *h)
     DevScope dev_scope_(h->device);
     if (dev_scope_.err != hipSuccess || flush_sync(h) != PSDC_OK)
         return nullptr;
-    psdc_handle *o = psdc_create(h->n, h->window_kind, h->n_channels, h->device);
+    psdc_handle *o = create_impl(h->n, h->window_kind, h->win_host.data(),
+                                 WindowConsts{h->nenbw, h->power, h->geo.overlap}, h->n_channels, h->device);
     if (!o)
         return nullptr;
     o->detrend = h->detrend;
@@ -2271,6 +2396,188 @@ int psdc_stitch(uint32_t n, int window_kind, uint32_t n_stages, const uint32_t *
                          breaks_cap, n_breaks);
     if (rc)
         return fail(nullptr, rc, "psdc_stitch: output too small");
+    return PSDC_OK;
+}
+
+int psdc_stitch_window(uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_stages,
+                       const uint64_t *counts64, const uint32_t *avgs, const uint64_t *pendings, const float *spectra,
+                       int keep_overlap, uint32_t min_count, int keep_transition_band, float *psd_out, size_t psd_cap,
+                       size_t *psd_len, psdc_break *breaks, size_t breaks_cap, size_t *n_breaks)
+{
+    if (n < 2 || overlap >= n || n_stages > 20)
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_stitch_window: bad arguments");
+    if (n_stages && (!counts64 || !avgs || !pendings || (psd_out && !spectra)))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_stitch_window: null input");
+    uint32_t counts[20];
+    for (uint32_t i = 0; i < n_stages; ++i)
+        counts[i] = count_report(counts64[i]);
+    int rc = stitch_impl(n, nenbw, power, (uint32_t)overlap, n_stages, counts, avgs, pendings, spectra, keep_overlap,
+                         min_count, keep_transition_band, psd_out, psd_cap, psd_len, breaks, breaks_cap, n_breaks, counts64);
+    if (rc)
+        return fail(nullptr, rc, "psdc_stitch_window: output too small");
+    return PSDC_OK;
+}
+
+// ---- packed read-out (include/psdcascade.h) ------------------------------------------------------
+// Layout (native endian, 8-byte aligned throughout):
+//   header   { u32 magic 'PSDR', u32 version, u32 n, u32 n_channels, f32 power, f32 nenbw, u32 overlap, u32 window_kind }
+//   channel  { u32 n_stages, u32 pad, stage[MAX_STAGES] { u64 count64, u64 pending, u32 avg, u32 pad },
+//              f32 spectra[MAX_STAGES][n/2 + 1 (+1 if even, to keep 8-byte alignment)] }   x n_channels
+} // extern "C"
+
+namespace {
+
+constexpr uint32_t PACK_MAGIC = 0x52445350u, PACK_VERSION = 1;
+struct PackHeader {
+    uint32_t magic, version, n, n_channels;
+    float power, nenbw;
+    uint32_t overlap, window_kind;
+};
+struct PackStage {
+    uint64_t count64, pending;
+    uint32_t avg, pad;
+};
+size_t pack_row_floats(uint32_t n) { return ((size_t)n / 2 + 1 + 1) & ~(size_t)1; }
+size_t pack_channel_bytes(uint32_t n) { return 8 + sizeof(PackStage) * MAX_STAGES + sizeof(float) * MAX_STAGES * pack_row_floats(n); }
+
+// header + bounds of a record; nullptr (and the error recorded) if it is not one
+const PackHeader *pack_check(const void *buf, size_t len, uint32_t channel)
+{
+    const PackHeader *hd = static_cast<const PackHeader *>(buf);
+    if (!buf || len < sizeof(PackHeader) || hd->magic != PACK_MAGIC || hd->version != PACK_VERSION || hd->n < 2 ||
+        len < sizeof(PackHeader) + (size_t)hd->n_channels * pack_channel_bytes(hd->n)) {
+        fail(nullptr, PSDC_ERR_ARG, "not a packed read-out (psdc_pack_readout) or truncated");
+        return nullptr;
+    }
+    if (channel >= hd->n_channels) {
+        fail(nullptr, PSDC_ERR_ARG, "channel out of range of the packed read-out");
+        return nullptr;
+    }
+    return hd;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t psdc_readout_bytes(uint32_t n, uint32_t n_channels)
+{
+    return sizeof(PackHeader) + (size_t)n_channels * pack_channel_bytes(n);
+}
+
+int psdc_pack_init(void *buf, size_t cap, uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_channels)
+{
+    if (!buf || n < 2 || overlap >= n || cap < psdc_readout_bytes(n, n_channels))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_init: bad arguments or buffer too small (psdc_readout_bytes)");
+    memset(buf, 0, psdc_readout_bytes(n, n_channels));
+    const PackHeader hd{PACK_MAGIC, PACK_VERSION, n, n_channels, power, nenbw, (uint32_t)overlap, 0};
+    memcpy(buf, &hd, sizeof(hd));
+    return PSDC_OK;
+}
+
+int psdc_pack_channel(void *buf, size_t len, uint32_t channel, uint32_t n_stages, const uint64_t *counts64,
+                      const uint32_t *avgs, const uint64_t *pendings, const float *spectra)
+{
+    const PackHeader *hd = pack_check(buf, len, channel);
+    if (!hd)
+        return PSDC_ERR_ARG;
+    if (n_stages > MAX_STAGES || (n_stages && (!counts64 || !avgs || !pendings || !spectra)))
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_channel: bad arguments");
+    char *p = static_cast<char *>(buf) + sizeof(PackHeader) + (size_t)channel * pack_channel_bytes(hd->n);
+    memset(p, 0, pack_channel_bytes(hd->n));
+    memcpy(p, &n_stages, sizeof(n_stages));
+    PackStage *ps = reinterpret_cast<PackStage *>(p + 8);
+    float *sp = reinterpret_cast<float *>(p + 8 + sizeof(PackStage) * MAX_STAGES);
+    const size_t bins = hd->n / 2 + 1, row = pack_row_floats(hd->n);
+    for (uint32_t k = 0; k < n_stages; ++k) {
+        ps[k] = {counts64[k], pendings[k], avgs[k], 0};
+        memcpy(sp + k * row, spectra + k * bins, sizeof(float) * bins);
+    }
+    return PSDC_OK;
+}
+
+int psdc_pack_readout(psdc_handle *h, void *buf, size_t cap, size_t *len)
+{
+    if (!h)
+        return fail(nullptr, PSDC_ERR_ARG, "null handle");
+    const size_t need = psdc_readout_bytes(h->n, h->n_channels);
+    if (len)
+        *len = need;
+    if (!buf)
+        return PSDC_OK; // size query
+    if (cap < need)
+        return fail(h, PSDC_ERR_CAPACITY, "psdc_pack_readout: buffer too small (psdc_readout_bytes)");
+    ON_DEVICE(h, h->device);
+    int rc = flush_sync(h);
+    if (rc)
+        return rc;
+    memset(buf, 0, need);
+    char *p = static_cast<char *>(buf);
+    PackHeader hd{PACK_MAGIC, PACK_VERSION, h->n, h->n_channels, h->power, h->nenbw, h->geo.overlap, (uint32_t)h->window_kind};
+    memcpy(p, &hd, sizeof(hd));
+    p += sizeof(hd);
+    const size_t bins = h->n / 2 + 1, row = pack_row_floats(h->n);
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci, p += pack_channel_bytes(h->n)) {
+        Channel &c = h->ch[ci];
+        const uint32_t ns = (uint32_t)c.st.size();
+        memcpy(p, &ns, sizeof(ns));
+        PackStage *ps = reinterpret_cast<PackStage *>(p + 8);
+        float *sp = reinterpret_cast<float *>(p + 8 + sizeof(PackStage) * MAX_STAGES);
+        for (uint32_t k = 0; k < ns; ++k)
+            ps[k] = {c.st[k].count64, pending_for(h->geo, c.st[k].total), cur_stage_avg(h, k), 0};
+        if (ns) { // the channel's accumulators are consecutive rows of one slab: one copy
+            HIPCHK(h, launch_copy_out(h->h_read, c.st[0].spectrum, (size_t)ns * h->n, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (uint32_t k = 0; k < ns; ++k)
+                memcpy(sp + k * row, h->h_read + (size_t)k * h->n, sizeof(float) * bins);
+        }
+    }
+    return PSDC_OK;
+}
+
+int psdc_unpack_info(const void *buf, size_t len, uint32_t channel, uint32_t *n, uint32_t *n_channels, uint32_t *n_stages)
+{
+    const PackHeader *hd = pack_check(buf, len, channel);
+    if (!hd)
+        return PSDC_ERR_ARG;
+    if (n)
+        *n = hd->n;
+    if (n_channels)
+        *n_channels = hd->n_channels;
+    if (n_stages)
+        memcpy(n_stages, static_cast<const char *>(buf) + sizeof(PackHeader) + (size_t)channel * pack_channel_bytes(hd->n), 4);
+    return PSDC_OK;
+}
+
+int psdc_unpack_stitch(const void *buf, size_t len, uint32_t channel, int keep_overlap, uint32_t min_count,
+                       int keep_transition_band, float *psd_out, size_t psd_cap, size_t *psd_len, psdc_break *breaks,
+                       size_t breaks_cap, size_t *n_breaks)
+{
+    const PackHeader *hd = pack_check(buf, len, channel);
+    if (!hd)
+        return PSDC_ERR_ARG;
+    const char *p = static_cast<const char *>(buf) + sizeof(PackHeader) + (size_t)channel * pack_channel_bytes(hd->n);
+    uint32_t ns = 0;
+    memcpy(&ns, p, 4);
+    if (ns > MAX_STAGES)
+        return fail(nullptr, PSDC_ERR_ARG, "packed read-out: stage count out of range");
+    const PackStage *ps = reinterpret_cast<const PackStage *>(p + 8);
+    const float *sp = reinterpret_cast<const float *>(p + 8 + sizeof(PackStage) * MAX_STAGES);
+    const size_t bins = hd->n / 2 + 1, row = pack_row_floats(hd->n);
+    uint32_t counts[MAX_STAGES], avgs[MAX_STAGES];
+    uint64_t counts64[MAX_STAGES], pend[MAX_STAGES];
+    std::vector<float> spectra((size_t)ns * bins);
+    for (uint32_t k = 0; k < ns; ++k) {
+        counts64[k] = ps[k].count64;
+        counts[k] = count_report(ps[k].count64);
+        avgs[k] = ps[k].avg;
+        pend[k] = ps[k].pending;
+        memcpy(spectra.data() + k * bins, sp + k * row, sizeof(float) * bins);
+    }
+    int rc = stitch_impl(hd->n, hd->nenbw, hd->power, hd->overlap, ns, counts, avgs, pend, spectra.data(), keep_overlap,
+                         min_count, keep_transition_band, psd_out, psd_cap, psd_len, breaks, breaks_cap, n_breaks, counts64);
+    if (rc)
+        return fail(nullptr, rc, "psdc_unpack_stitch: output too small");
     return PSDC_OK;
 }
 
@@ -2450,6 +2757,22 @@ psdc_stage *psdc_stage_create(uint32_t n, int window_kind, int device)
     return st;
 }
 
+psdc_stage *psdc_stage_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap, int device)
+{
+    psdc_handle *h = psdc_create_window(n, win, power, nenbw, overlap, 1, device);
+    if (!h)
+        return nullptr;
+    h->stage_limit = 1;
+    psdc_stage *st = new (std::nothrow) psdc_stage();
+    if (!st) {
+        psdc_destroy(h);
+        fail(nullptr, PSDC_ERR_NOMEM, "psdc_stage_create_window: out of memory");
+        return nullptr;
+    }
+    st->h = h;
+    return st;
+}
+
 void psdc_stage_destroy(psdc_stage *st)
 {
     if (!st)
@@ -2544,8 +2867,14 @@ int psdc_stage_process_device(psdc_stage *st, const float *d_x, size_t len, floa
         StageState &sk = c.st[1];
         avail = sk.total - sk.sink_pos;
         if (avail) {
-            if (!d_y || cap < avail)
-                return fail(h, PSDC_ERR_CAPACITY, "psdc_stage_process_device: y too small");
+            if (!d_y || cap < avail) {
+                // x has been consumed (as in the reference, which panics AFTER buffering, src/psd.rs:201-253) and
+                // the enqueued kernels may still be reading d_x: wait for them, so that d_x is free on return as
+                // documented; the outputs stay pending and a later call with room returns them
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                (void)release_retired(h);
+                return fail(h, PSDC_ERR_CAPACITY, "psdc_stage_process_device: y too small (x was consumed; the outputs stay pending)");
+            }
             HIPCHK(h, hipMemcpyAsync(d_y, sk.buf.p[sk.buf.cur] + (sk.sink_pos - sk.buf.base), sizeof(float) * avail,
                                      hipMemcpyDeviceToDevice, h->stream));
             sk.sink_pos = sk.total;

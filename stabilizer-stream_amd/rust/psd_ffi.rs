@@ -9,12 +9,18 @@
 //! build.rs:  println!("cargo:rustc-link-lib=dylib=psdcascade");
 //!            println!("cargo:rustc-link-search=native={}", env!("PSDCASCADE_LIB_DIR"));
 
+use rustfft::Fft;
 use std::ffi::CStr;
 use std::ops::Range;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 use std::ptr::NonNull;
+use std::sync::Arc;
 
-pub use crate::psd::{AvgOpts, Break, Detrend, MergeOpts}; // plain data types stay the reference's own
+pub use crate::psd::{AvgOpts, Break, Detrend, MergeOpts, Window}; // plain data types stay the reference's own
+
+/// `device` argument meaning "the index in $PSDC_DEVICE, 0 when unset" (include/psdcascade.h): what the constructors
+/// with the reference's signatures pass, so that one process per GPU is placed from outside (`PSDC_DEVICE=3 psd ...`).
+const PSDC_DEVICE_DEFAULT: c_int = -1;
 
 #[repr(C)]
 struct PsdcHandle {
@@ -39,6 +45,15 @@ struct PsdcBreak {
 
 extern "C" {
     fn psdc_create(n: u32, window_kind: c_int, n_channels: u32, device: c_int) -> *mut PsdcHandle;
+    fn psdc_create_window(n: u32, win: *const f32, power: f32, nenbw: f32, overlap: usize, n_channels: u32,
+                          device: c_int) -> *mut PsdcHandle;
+    fn psdc_readout_bytes(n: u32, n_channels: u32) -> usize;
+    fn psdc_pack_readout(h: *mut PsdcHandle, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
+    fn psdc_unpack_stitch(
+        buf: *const c_void, len: usize, channel: u32, keep_overlap: c_int, min_count: u32, keep_transition_band: c_int,
+        psd_out: *mut f32, psd_cap: usize, psd_len: *mut usize,
+        breaks: *mut PsdcBreak, breaks_cap: usize, n_breaks: *mut usize,
+    ) -> c_int;
     fn psdc_destroy(h: *mut PsdcHandle);
     fn psdc_clone(h: *mut PsdcHandle) -> *mut PsdcHandle;
     fn psdc_set_detrend(h: *mut PsdcHandle, kind: c_int) -> c_int;
@@ -102,36 +117,76 @@ impl<const N: usize> PsdCascade<N> {
                      p.as_mut_ptr(), p.len(), &mut plen, b.as_mut_ptr(), b.len(), &mut nb)
         });
         p.truncate(plen);
-        let breaks = b[..nb]
-            .iter()
-            .map(|b| Break {
-                start: b.start as usize,
-                include: b.include != 0,
-                count: b.count,
-                avg: b.avg,
-                bins: Range { start: b.bins_start as usize, end: b.bins_end as usize },
-                fft_size: b.fft_size as usize,
-                decimation: b.decimation as usize,
-                pending: b.pending as usize,
-                processed: b.processed as usize,
-            })
-            .collect();
-        (p, breaks)
+        (p, b[..nb].iter().map(to_break).collect())
+    }
+
+    /// A cascade on a given HIP device, or over a caller-built window: the reference has neither constructor
+    /// (`Default` plans Hann on the CPU, src/psd.rs:408-423); `default()` == `with(Window::hann(), PSDC_DEVICE)`.
+    pub fn with_device(device: i32) -> Self {
+        const HANN: c_int = 1;
+        Self(nonnull_or_panic(unsafe { psdc_create(N as u32, HANN, 1, device as c_int) }))
+    }
+    pub fn with_window(win: &Window<N>, device: i32) -> Self {
+        Self(nonnull_or_panic(unsafe {
+            psdc_create_window(N as u32, win.win.as_ptr(), win.power, win.nenbw, win.overlap, 1, device as c_int)
+        }))
+    }
+
+    /// The raw accumulators and counters of this cascade as a flat, fixed-size byte record
+    /// (`Self::READOUT_BYTES`, the same for every cascade of this N): what a multi-GPU host gathers -- with RCCL,
+    /// MPI, a socket or a memcpy between the handles of one process -- and stitches with [`psd_from_readout`].
+    pub fn pack_readout(&self) -> Vec<u8> {
+        let mut buf = vec![0u8; unsafe { psdc_readout_bytes(N as u32, 1) }];
+        let mut len = 0usize;
+        self.check(unsafe { psdc_pack_readout(self.0.as_ptr(), buf.as_mut_ptr() as *mut c_void, buf.len(), &mut len) });
+        buf
     }
 }
 
+fn nonnull_or_panic(h: *mut PsdcHandle) -> NonNull<PsdcHandle> {
+    NonNull::new(h).unwrap_or_else(|| {
+        let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
+        panic!("psdcascade: {}", msg.to_string_lossy())
+    })
+}
+
+fn to_break(b: &PsdcBreak) -> Break {
+    Break {
+        start: b.start as usize,
+        include: b.include != 0,
+        count: b.count,
+        avg: b.avg,
+        bins: Range { start: b.bins_start as usize, end: b.bins_end as usize },
+        fft_size: b.fft_size as usize,
+        decimation: b.decimation as usize,
+        pending: b.pending as usize,
+        processed: b.processed as usize,
+    }
+}
+
+/// `PsdCascade::psd` (src/psd.rs:479-543) of one gathered record: bit-identical to `psd()` on the cascade that
+/// packed it (raw accumulators travel; the 64-bit counts the library normalises by travel with them).
+pub fn psd_from_readout<const N: usize>(record: &[u8], opts: &MergeOpts) -> (Vec<f32>, Vec<Break>) {
+    let mut p = vec![0f32; 16 * (N / 2 + 1)];
+    let mut b = vec![PsdcBreak::default(); 16];
+    let (mut plen, mut nb) = (0usize, 0usize);
+    let rc = unsafe {
+        psdc_unpack_stitch(record.as_ptr() as *const c_void, record.len(), 0, opts.keep_overlap as c_int, opts.min_count,
+                           opts.keep_transition_band as c_int, p.as_mut_ptr(), p.len(), &mut plen, b.as_mut_ptr(),
+                           b.len(), &mut nb)
+    };
+    if rc < 0 {
+        let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
+        panic!("psdcascade: {}", msg.to_string_lossy());
+    }
+    p.truncate(plen);
+    (p, b[..nb].iter().map(to_break).collect())
+}
+
 impl<const N: usize> Default for PsdCascade<N> {
-    /// Hann window, Detrend::None, AvgOpts::default() (src/psd.rs:408-423)
+    /// Hann window, Detrend::None, AvgOpts::default() (src/psd.rs:408-423), on the device $PSDC_DEVICE names
     fn default() -> Self {
-        const HANN: c_int = 1;
-        let h = unsafe { psdc_create(N as u32, HANN, 1, 0) };
-        match NonNull::new(h) {
-            Some(h) => Self(h),
-            None => {
-                let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
-                panic!("psdcascade: {}", msg.to_string_lossy())
-            }
-        }
+        Self::with_device(PSDC_DEVICE_DEFAULT)
     }
 }
 
@@ -161,7 +216,7 @@ struct PsdcStage {
 }
 
 extern "C" {
-    fn psdc_stage_create(n: u32, window_kind: c_int, device: c_int) -> *mut PsdcStage;
+    fn psdc_stage_create_window(n: u32, win: *const f32, power: f32, nenbw: f32, overlap: usize, device: c_int) -> *mut PsdcStage;
     fn psdc_stage_destroy(s: *mut PsdcStage);
     fn psdc_stage_clone(s: *mut PsdcStage) -> *mut PsdcStage;
     fn psdc_stage_set_avg(s: *mut PsdcStage, avg: u32) -> c_int;
@@ -194,10 +249,22 @@ impl<const N: usize> Psd<N> {
         }
     }
 
-    /// `Psd::new(fft, win)` (src/psd.rs:137): the FFT plan is the library's own; `hann` selects
-    /// `Window::hann()` / `Window::rectangular()`.
-    pub fn new(hann: bool) -> Self {
-        let s = unsafe { psdc_stage_create(N as u32, hann as c_int, 0) };
+    /// `Psd::new(fft, win)` with the reference's signature (src/psd.rs:137-152): `win` is ANY `Window<N>` -- the
+    /// struct is public with public fields (src/psd.rs:12-20) -- and is uploaded as it is; a table equal to
+    /// `Window::hann()` keeps the single-pass fused kernels, any other runs the generic two-pass kernels.  The plan
+    /// `fft` is only held to the reference's assertion: the transform itself is the library's own hand-written FFT of
+    /// the same length (an unnormalised forward DFT is an unnormalised forward DFT).
+    pub fn new(fft: Arc<dyn Fft<f32>>, win: Arc<Window<N>>) -> Self {
+        const { assert!(N >= 2) } // Nyquist and DC distinction (src/psd.rs:138)
+        assert_eq!(N, fft.len()); // FFT and decimation block size compatibility (src/psd.rs:139)
+        Self::with_device(win, PSDC_DEVICE_DEFAULT)
+    }
+
+    /// the same on a given HIP device
+    pub fn with_device(win: Arc<Window<N>>, device: i32) -> Self {
+        let s = unsafe {
+            psdc_stage_create_window(N as u32, win.win.as_ptr(), win.power, win.nenbw, win.overlap, device as c_int)
+        };
         let s = NonNull::new(s).unwrap_or_else(|| {
             let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
             panic!("psdcascade: {}", msg.to_string_lossy())

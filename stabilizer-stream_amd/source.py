@@ -40,23 +40,25 @@ class Source:
         self.received = 0  # Loss (src/loss.rs) for the get() path
         self.dropped = 0
         self._seq = None
+        self.eof = False  # a raw file is exhausted (get() then returns empty traces, like the reference)
 
     def close(self):
         self._f.close()
 
     # -- reference-granularity path -------------------------------------------------
     def get(self):
-        """One reference-sized chunk: [(name, np.float32 array)], or raises EOFError at end of file."""
+        """One reference-sized chunk: [(name, np.float32 array)].  End of file without --repeat, as in the reference:
+        Data::Raw keeps answering with an EMPTY "raw" trace (`read` returns 0 bytes, src/source.rs:151-157; also for a
+        tail shorter than one f32) and sets `self.eof`; Data::File raises EOFError (`read_exact` -> UnexpectedEof,
+        src/source.rs:137-146)."""
         if self.opts.raw is not None:
-            while True:
+            buf = self._f.read(self.RAW_CHUNK)
+            if len(buf) == 0 and self.opts.repeat:  # src/source.rs:152-155
+                self._f.seek(0)
                 buf = self._f.read(self.RAW_CHUNK)
-                if len(buf) == 0:
-                    if self.opts.repeat and os.path.getsize(self.opts.raw) >= 4:
-                        self._f.seek(0)
-                        continue
-                    raise EOFError
-                n = len(buf) // 4 * 4  # bytemuck::cast_slice(&buf[..len / 4 * 4]) (src/source.rs:156)
-                return [("raw", np.frombuffer(buf[:n], dtype="<f4").astype(np.float32))]
+            self.eof = len(buf) == 0
+            n = len(buf) // 4 * 4  # bytemuck::cast_slice(&buf[..len / 4 * 4]) (src/source.rs:156)
+            return [("raw", np.frombuffer(buf[:n], dtype="<f4").astype(np.float32))]
         while True:
             buf = self._f.read(self.opts.frame_size)
             if len(buf) < self.opts.frame_size:

@@ -76,7 +76,7 @@ int main()
         std::vector<float> xs(total), ys(total >> 3);
         for (auto &v : xs)
             v = (u(rng) - 0.5f) * std::sqrt(12.0f);
-        Psd<N> s; // Psd::<N>::new(plan_fft_forward(N), Arc::new(Window::hann()))
+        Psd<N> s(N, Window<N>::hann()); // Psd::<N>::new(FftPlanner::new().plan_fft_forward(N), Arc::new(Window::hann()))
         const auto out = s.process(xs, ys);
         if (out.size() != (xs.size() >> 3) - (size_t)psdc_hbf_response_length(3)) { // :622
             std::fprintf(stderr, "Psd::process returned %zu items\n", out.size());
@@ -87,6 +87,59 @@ int main()
             if (std::fabs(p * g * 0.5 - 1.0) > 10.0 / std::sqrt((double)s.count())) // :623-632
                 ++bad;
         std::printf("Psd<%zu>: %zu outputs, count %u, %zu pending\n", N, out.size(), s.count(), s.buf().size());
+        // a Window<N> built by the caller (pub fields, src/psd.rs:12-20): Hann's weights rebuilt by hand must be
+        // recognised as Hann (same fused kernels, same bits); a flat-top-ish table must go through and normalise
+        Window<N> mine;
+        mine.win.resize(N);
+        const float df = 3.14159265358979323846f / (float)N;
+        for (size_t i = 0; i < N; ++i) {
+            const float sn = std::sin(df * (float)i);
+            mine.win[i] = sn * sn;
+        }
+        mine.power = 0.25f;
+        mine.nenbw = 1.5f;
+        mine.overlap = N / 2;
+        Psd<N> s2(N, mine);
+        std::vector<float> y2(total >> 3);
+        s2.process(xs, y2);
+        if (s2.spectrum() != s.spectrum() || s2.count() != s.count())
+            ++bad;
+        bool threw = false;
+        try {
+            Psd<N> wrong(N / 2, mine); // assert_eq!(N, fft.len()) src/psd.rs:139
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        if (!threw)
+            ++bad;
+        double m1 = 0.0, m2 = 0.0;
+        for (size_t i = 0; i < N; ++i) { // Hamming, hop N/4
+            mine.win[i] = 0.54f - 0.46f * std::cos(2.0f * df * (float)i);
+            m1 += mine.win[i];
+            m2 += (double)mine.win[i] * mine.win[i];
+        }
+        m1 /= N;
+        m2 /= N;
+        mine.power = (float)(m1 * m1);
+        mine.nenbw = (float)(m2 / (m1 * m1));
+        mine.overlap = 3 * N / 4;
+        PsdCascade<N> hc(mine);
+        hc.process(xs);
+        const auto [ph, bh] = hc.psd(MergeOpts{});
+        size_t off = 0;
+        for (const Break &b : bh) {
+            const size_t len = b.include ? b.bins.second - b.bins.first : 0;
+            for (size_t i = 0; i < len; ++i)
+                if (std::fabs(ph[off + i] * 0.5 - 1.0) > 10.0 / std::sqrt((double)b.count)) // white noise reads PSD = 2 whatever the window
+                    ++bad;
+            off += len;
+        }
+        // the packed read-out stitches to the same bits
+        const auto rec = hc.pack_readout();
+        const auto [pr, brr] = psd_from_readout(rec);
+        if (pr != ph || brr.size() != bh.size())
+            ++bad;
+        std::printf("caller-built windows: Hann table recognised, Hamming cascade %zu stages, record %zu bytes\n", bh.size(), rec.size());
     }
     // the batched feeder (cpp/source.hpp): a raw f32 file as stream_to_raw writes it (src/bin/stream_to_raw.rs:24-25),
     // ingested in 100 kB reads through Source::feed, must give the same PSD as process() on the same samples

@@ -28,7 +28,7 @@ int main(int argc, char **argv)
         Source s(o);
         Traces t;
         size_t got = 0, calls = 0;
-        while (s.get(t)) {
+        while (s.get(t) && !s.at_eof()) {
             if (t.size() != 1 || std::string(t[0].first) != "raw" || t[0].second.size() > 512)
                 ++bad;
             for (float v : t[0].second)
@@ -38,6 +38,10 @@ int main(int argc, char **argv)
         }
         if (got != x.size() || calls != 3)
             ++bad;
+        // past the end without --repeat the reference keeps answering Ok(vec![("raw", vec![])]) (src/source.rs:151-157)
+        for (int i = 0; i < 3; ++i)
+            if (!s.get(t) || t.size() != 1 || std::string(t[0].first) != "raw" || !t[0].second.empty() || !s.at_eof())
+                ++bad;
         o.repeat = true;
         Source r(o);
         size_t n = 0;

@@ -789,8 +789,8 @@ def test_config4_one_gpu_share_full_size(pkg, ora, gpu_required):
             if segs:
                 assert_psd_close(g.stage_spectrum(c, k), one.stage_spectrum(0, k), f"channel {c} stage {k}")
         one.close()
-    spec, meta = shard.pack_readout(g, nch, n)
-    merged = shard.stitch_gathered(pkg, n, [spec], [meta], [nch])
+    rec = shard.pack_readout(g, nch, n, pkg)
+    merged = shard.stitch_gathered(pkg, [rec], [nch])
     for c in range(nch):
         p, br = g.psd(c)
         assert np.array_equal(merged[c][0], p) and len(merged[c][1]) == len(br)
@@ -1224,8 +1224,8 @@ def test_sixty_four_channel_bank(pkg, ora, gpu_required):
                 g.process_device(c, ds[c].data_ptr() + 4 * off, m)
     for c in range(0, nch, 9):
         check_against_oracle(pkg, ora, g, [xs[c]], n, channel=c, what=f"channel {c} of 64", pure_min_count=4)
-    spec, meta = shard.pack_readout(g, nch, n)
-    merged = shard.stitch_gathered(pkg, n, [spec], [meta], [nch])
+    rec = shard.pack_readout(g, nch, n, pkg)
+    merged = shard.stitch_gathered(pkg, [rec], [nch])
     for c in range(nch):
         p, br = g.psd(c)
         assert np.array_equal(merged[c][0], p)

@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), f"libpsdcascade.so does not export {name}"
     assert sorted(pkg.EXPORTS) == declared
-    assert L.psdc_abi_version() == 2
+    assert L.psdc_abi_version() == 3
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (psdc_[a-z0-9_]+)", out))
     assert exported == set(declared)
@@ -188,3 +188,73 @@ def test_header_is_plain_c(tmp_path):
                     "-o", str(exe), "-L", lib_dir, "-lpsdcascade", "-L/opt/rocm/lib", "-lamdhip64",
                     f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     assert subprocess.run([str(exe)]).returncode == 0  # pure host entry points: no GPU needed
+
+
+def test_window_tables_match_the_reference_construction(pkg, ora):
+    """psdc_window_table = Window::hann() / Window::rectangular() (src/psd.rs:24-55) exactly as the f32 oracle
+    restates them, weights and constants; nenbw * power = mean(w^2) (what gain() relies on, src/psd.rs:279-283)."""
+    for n in (16, 512, 1024, 16384):
+        for kind, name in ((pkg.Window.HANN, "hann"), (pkg.Window.RECTANGULAR, "rect")):
+            t = pkg.WindowTable._kind(n, kind)
+            w, p, e, ov = ora.window(n, name, "f32")
+            assert np.array_equal(t.win, w) and (t.power, t.nenbw, t.overlap) == (p, e, ov)
+            assert abs(t.nenbw * t.power - float(np.mean(t.win.astype(np.float64) ** 2))) < 1e-6
+    with pytest.raises(pkg.PsdError):
+        pkg.WindowTable._kind(512, 7)
+
+
+def test_create_window_rejects_bad_tables_before_touching_a_device(pkg):
+    """(N - overlap) % 8 != 0 panics in the reference at the first decimation (src/psd.rs:246-247), overlap >= N
+    underflows `N - overlap`: both are PSDC_ERR_ARG at construction, GPU or not."""
+    n = 256
+    t = pkg.WindowTable.hann(n)
+    for bad in (n, n + 8, n - 4, 3):
+        with pytest.raises(pkg.PsdError) as e:
+            pkg.PsdCascadeBank(n, window=pkg.WindowTable(t.win, t.power, t.nenbw, bad))
+        assert "overlap" in str(e.value)
+        with pytest.raises(pkg.PsdError) as e:
+            pkg.Psd(n, pkg.WindowTable(t.win, t.power, t.nenbw, bad))
+        assert "overlap" in str(e.value)
+    with pytest.raises(pkg.PsdError) as e:
+        pkg.Psd.new(n // 2, t)
+    assert "fft.len()" in str(e.value)  # assert_eq!(N, fft.len()) src/psd.rs:139
+
+
+def test_packed_record_roundtrip_and_64_bit_counts(pkg, ora):
+    """psdc_pack_init / psdc_pack_channel / psdc_unpack_stitch (pure host): a record built from the oracle's stage
+    data stitches bit-identically to psdc_stitch on the same data; with a count past 2^32 the record's 64-bit count
+    normalises like single-GPU psd() (gain() of the 64-bit count) while the u32 view saturates."""
+    n = 64
+    x = np.random.default_rng(11).standard_normal(900 * n).astype(np.float32)
+    chans = []
+    for seed in range(3):
+        o = ora.PsdCascade(n, "f32")
+        o.process(np.roll(x, 17 * seed))
+        infos = [o.stage_info(k) for k in range(o.num_stages)]
+        chans.append(([i["count"] for i in infos], [i["avg"] for i in infos], [i["pending"] for i in infos],
+                      np.stack([o.stage_spectrum(k) for k in range(o.num_stages)])))
+    rec = pkg.pack_record(n, chans, rows=5)  # padded to the largest shard of a gather
+    assert rec.size == pkg.readout_bytes(n, 5)
+    for c, (counts, avgs, pend, sp) in enumerate(chans):
+        assert pkg.unpack_info(rec, c) == (n, 5, len(counts))
+        for opts in (pkg.MergeOpts(), pkg.MergeOpts(True, 0, True), pkg.MergeOpts(False, 3, False)):
+            p, br = pkg.stitch(n, counts, avgs, pend, sp, opts)
+            q, bq = pkg.unpack_stitch(rec, c, opts)
+            assert np.array_equal(p, q, equal_nan=True) and br == bq
+    assert pkg.unpack_info(rec, 4) == (n, 5, 0) and pkg.unpack_stitch(rec, 4)[0].size == 0  # padding channels are empty
+    with pytest.raises(pkg.PsdError):
+        pkg.unpack_stitch(rec[:100], 0)
+    # past 2^32 segments
+    counts, avgs, pend, sp = chans[0]
+    big = [counts[0] + (1 << 33)] + list(counts[1:])
+    rec2 = pkg.pack_record(n, [(big, avgs, pend, sp)])
+    q, bq = pkg.unpack_stitch(rec2, 0)
+    p64, b64 = pkg.stitch(n, big, avgs, pend, sp)  # routes through psdc_stitch_window (64-bit counts)
+    assert np.array_equal(q, p64) and bq == b64
+    top = bq[-1]  # stage 0 is the last break (highest rate)
+    assert top.count == 0xFFFFFFFF  # the u32 the ABI reports saturates (the reference's wraps)
+    sl = slice(top.start, top.start + len(top.bins))
+    expect = sp[0][top.bins.start:top.bins.stop] / (np.float32((n // 2) * big[0]) * np.float32(1.5) * np.float32(0.25))
+    assert np.allclose(q[sl], expect, rtol=1e-6)
+    psat, _ = pkg.stitch(n, [0xFFFFFFFF] + list(counts[1:]), avgs, pend, sp)  # what a u32 gather would have given
+    assert not np.allclose(psat[sl], q[sl], rtol=1e-3)

@@ -46,11 +46,12 @@ def _worker(rank, world, port, n, n_channels, total, out_path):
     streams = [pkg.noise_host(total + 1000 * g, 0x7654321 + g) for g in mine]
     bank = OracleBank(ora, n, streams)
     width = max(len(shard.channel_shard(n_channels, world, r)) for r in range(world))
-    spec, meta = shard.pack_readout(bank, len(mine), n, pad_to=width)  # equal blocks for the gather
-    specs, metas = shard.gather_readout(dist, spec, meta)
+    rec = shard.pack_readout(bank, len(mine), n, pkg, pad_to=width)  # equal blocks for the gather
+    assert rec.size == pkg.readout_bytes(n, width)
+    recs = shard.gather_readout(dist, rec)
     if rank == 0:
         per_rank = [len(shard.channel_shard(n_channels, world, r)) for r in range(world)]
-        res = shard.stitch_gathered(pkg, n, specs, metas, per_rank)
+        res = shard.stitch_gathered(pkg, recs, per_rank)
         ok = len(res) == n_channels
         for g, (p, br) in enumerate(res):
             ref = ora.PsdCascade(n, "f32")

@@ -18,13 +18,15 @@ def test_raw_get_granularity_and_repeat(pkg, tmp_path):
     got = []
     sizes = []
     while True:
-        try:
-            (name, v), = s.get()
-        except EOFError:
-            break
+        (name, v), = s.get()
         assert name == "raw"
+        if s.eof:
+            break
         sizes.append(v.size)
         got.append(v)
+    for _ in range(3):  # past the end the reference keeps returning Ok(vec![("raw", vec![])]) (src/source.rs:151-157)
+        (name, v), = s.get()
+        assert name == "raw" and v.size == 0 and s.eof
     assert sizes == [512, 512, 276]  # <= 2048 B per call (src/source.rs:150-157)
     assert np.array_equal(np.concatenate(got), x)
     r = source.Source(source.SourceOpts(raw=_raw_file(tmp_path, x), repeat=True))
@@ -75,10 +77,10 @@ def test_feeders_on_gpu(pkg, ora, gpu_required, tmp_path):
     small = pkg.PsdCascadeBank(n)
     s = source.Source(source.SourceOpts(raw=path))
     while True:
-        try:
-            small.process(0, s.get()[0][1])
-        except EOFError:
+        v = s.get()[0][1]
+        if s.eof:
             break
+        small.process(0, v)
     for k in range(bulk.num_stages()):
         assert bulk.stage_info(0, k) == small.stage_info(0, k)
         a, b = bulk.stage_spectrum(0, k), small.stage_spectrum(0, k)

@@ -100,15 +100,17 @@ PY
   ;;
 record)
   tag=$1; shift
+  if [ -n "$PSDC_LIB" ]; then echo "record: PSDC_LIB is set ($PSDC_LIB): a record is of the default build only"; exit 2; fi
   "$0" tests || exit $?
   "$0" bench || exit $?
   "$0" stats "$tag" || exit $?
   "$0" pmc "$tag" || exit $?
   echo "record $tag complete: python tools/make_profile_summary.py $tag" ;;
 variants)
+  # each variant is loaded through $PSDC_LIB: the shipped stabilizer-stream_amd/libpsdcascade.so is never overwritten
+  # (the PSDK_ABL builds give wrong results on purpose; a later tests / bench / record must not run against one)
   for so in tools/variants/*.so; do
-    cp "$so" stabilizer-stream_amd/libpsdcascade.so
-    line "$*"; rc=$?; echo "   ^ $so"; if killed $rc; then exit $rc; fi
+    PSDC_LIB="$R/$so" line "$*"; rc=$?; echo "   ^ $so"; if killed $rc; then exit $rc; fi
   done ;;
 ranks)
   n=$1; shift
