@@ -32,21 +32,50 @@ ALG_BYTES_PER_SAMPLE = 4.0   # each raw f32 sample crosses HBM o
 ALG_FLOP_PER_SAMPLE = {1024: 78.0, 4096: 89.0, 16384: 100.0}
 
 
-def cpu_baseline(n, seconds=12.0):
-    """Time the CPU oracle (C restatement, f32) on this host: one thread, process() calls of
-    65536 samples like the reference's `insn` bench (src/psd.rs:554-559)."""
+def cpu_baseline(n, seconds=12.0, threads=1):
+    """Time the CPU oracle (C restatement, f32) on this host's cores: process() calls of 65536 samples like the
+    reference's `insn` bench (src/psd.rs:554-559), one cascade per thread (min(channels, cores)
+    threads, one channel per thread).  The library is REBUILT here with this host's -march=native first.  `value` is
+    the build with the radix-4 FFT whose loops gcc vectorises (a fairer stand-in for rustfft's SIMD butterflies); the
+    scalar radix-2 FFT every parity test sees and N = 512 (the size the reference's own figure is quoted for) ride along."""
+    import threading
     ora = entry.load_oracle()
+    try:
+        ora.build(force=True)  # gcc -O3 -march=native on THIS host (the shipped .so was built elsewhere)
+        rebuilt = True
+    except Exception:
+        rebuilt = False
     pkg = entry.load_package()
-    x = pkg.noise_host(1 << 16, 0x7654321)
-    c = ora.PsdCascade(n, "f32")
-    c.process(x)  # warm
-    t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(16):
-            c.process(x)
-        done += 16 * x.size
-    dt = time.perf_counter() - t0
+    xs = [pkg.noise_host(1 << 16, 0x7654321 + t) for t in range(threads)]
+
+    def leg(nn, fast, secs):
+        done = [0] * threads
+
+        def work(t):
+            c = ora.PsdCascade(nn, "f32")
+            if fast:
+                c.set_fast_fft()
+            c.process(xs[t])  # warm
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < secs:
+                for _ in range(8):
+                    c.process(xs[t])
+                k += 8
+            done[t] = k
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]  # ctypes releases the GIL in the C calls
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(done) * (1 << 16) / dt / 1e6, sum(done), dt
+
+    v_fast, calls, dt = leg(n, True, seconds * 0.5)
+    v_r2, _, _ = leg(n, False, seconds * 0.25)
+    v_512, _, _ = leg(512, True, seconds * 0.25)
     model = "?"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -55,11 +84,14 @@ def cpu_baseline(n, seconds=12.0):
                 break
     except OSError:
         pass
-    return {"value": done / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+    return {"value": v_fast, "unit": "MS/s", "cores": threads, "kind": "port",
+            "scalar_radix2_fft_value": v_r2, "n512_value": v_512,
             "host": f"{model}, {os.cpu_count()} logical cores visible",
-            "sample": f"{done} samples ({done // x.size} process() calls of 65536) in {dt:.1f} s, "
-                      f"C restatement of src/psd.rs (oracle/, f32, gcc -O3 -march=native), not the Rust crate; "
-                      f"reference quotes >200 MS/s/core for N=512 (README.md:11)"}
+            "rebuilt_on_this_host": rebuilt,
+            "sample": f"{calls} process() calls of 65536 samples over {threads} thread(s) (one cascade each) in {dt:.1f} s, N={n}; "
+                      f"C restatement of src/psd.rs (oracle/, f32, gcc -O3 -march=native), not the Rust crate: `value` with a "
+                      f"radix-4 Stockham FFT gcc vectorises, `scalar_radix2_fft_value` with the scalar radix-2 FFT of the parity "
+                      f"tests, `n512_value` = N=512 for the reference's own figure (>200 MS/s/core, N=512, README.md:11, src/psd.rs:550)"}
 
 
 def host_fed_rate(pkg, n, device, seconds=2.0):
@@ -80,6 +112,78 @@ def host_fed_rate(pkg, n, device, seconds=2.0):
     return {"value": done / dt / 1e6, "unit": "MS/s",
             "note": "host numpy buffer -> psdc_process (copy to pinned staging split over <= 4 host threads, "
                     "hipMemcpyAsync, kernels); link-bound"}
+
+
+def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None):
+    """A short untimed-by-`value` leg of the same cascade at another shape: 1 channel raw f32, 2^log2_batch samples
+    resident in HBM, passes until `seconds` have gone by.  Returns value + kernel-only roofline like the headline's."""
+    T = 1 << log2_batch
+    if buf is None or buf.numel() != T:
+        buf = torch.empty(T, dtype=torch.float32, device="cuda")
+        pkg.fill_noise_device(buf.data_ptr(), T, seed=0x7654321, device=device)
+        torch.cuda.synchronize()
+    bank = pkg.PsdCascadeBank(n, 1, device=device)
+    for _ in range(4):
+        bank.process_device(0, buf.data_ptr(), T)
+    bank.sync()
+    bank.configure(profile=True)
+    t0 = time.perf_counter()
+    passes = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            bank.process_device(0, buf.data_ptr(), T)
+        passes += 8
+    ns = bank.num_stages(0)
+    bank.psd(0)  # read-out inside the timed region, like the headline
+    dt = time.perf_counter() - t0
+    prof = bank.profile_read()
+    bank.close()
+    kern_s = prof["kernel_ms"] * 1e-3
+    ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
+    return {"value": passes * T / dt / 1e6, "unit": "MS/s",
+            "workload": f"1-channel raw f32, PsdCascade N={n}, {passes} passes over 2^{log2_batch} samples resident in HBM ({T * 4 >> 20} MiB), {ns} stages",
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                         "end_to_end_frac": ALG_BYTES_PER_SAMPLE * passes * T / dt / 1e9 / HBM_PEAK_GBPS,
+                         "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"])}}
+
+
+def side_leg_frames(pkg, torch, device, seconds, n=4096, batches=22, log2_per_trace=24):
+    """BASELINE configs[2]: 4-trace AdcDac ("dual-iir") frame stream, N=4096, frames resident in HBM
+    (psdc_process_adcdac_frames_device).  Algorithmic bytes = n_frames x frame_size."""
+    nframes = (1 << log2_per_trace) // (batches * 8)
+    rng = np.random.default_rng(1)
+    raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8), dtype=np.float32) * 4096), -32768, 32767).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, batches)
+    d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    bank = pkg.PsdCascadeBank(n, 4, device=device)
+    for _ in range(3):
+        bank.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+    bank.sync()
+    bank.configure(profile=True)
+    t0 = time.perf_counter()
+    calls = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            bank.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+        calls += 4
+    ns = bank.num_stages(0)
+    for c in range(4):
+        bank.psd(c)
+    dt = time.perf_counter() - t0
+    prof = bank.profile_read()
+    loss = bank.loss()
+    bank.close()
+    kern_s = prof["kernel_ms"] * 1e-3
+    nbytes = float(calls) * nframes * fs
+    ach = nbytes / kern_s / 1e9 if kern_s > 0 else 0.0
+    return {"value": calls * raw.size / dt / 1e6, "unit": "MS/s (samples of the four traces)",
+            "workload": f"BASELINE configs[2]: 4-trace AdcDac frames ({batches} batches, {fs} B) resident in HBM, PsdCascade N={n}, "
+                        f"{calls} calls of {nframes} frames (2^{log2_per_trace} samples per trace), {ns} stages; Loss {loss}",
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                         "end_to_end_frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_sample": fs / (batches * 8.0 * 4),
+                         "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
+                         "note": "achieved = n_frames x frame_size / time of the dominant (fused) launches; end_to_end_frac over wall time"}}
 
 
 def measured_traffic(kernel, n, channels, samples):
@@ -146,6 +250,9 @@ def main():
     ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short side legs after the headline (configs[2] frames, configs[4] N=16384, 2^28-sample footprint)")
+    ap.add_argument("--side-seconds", type=float, default=1.5, help="wall time of each side leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -329,8 +436,11 @@ def main():
                          # launches hold 1..PSDC_OPT_COALESCE spans of 2^log2_batch samples: both per-launch
                          # figures are for the AVERAGE launch of the timed region; the PMC traffic is measured
                          # per one-span launch (--coalesce 1) and scaled by the spans per launch
+                         # NOT measured by this run: the PMC passes on record for this shape (profiles/*_traffic.json), scaled
+                         "traffic_from_profiles": (tr["hbm_bytes_per_launch"] * prof["stage0_samples"] / max(1, prof["launches"]) / (T * C)
+                                                   if tr else None),
                          "traffic": (tr["hbm_bytes_per_launch"] * prof["stage0_samples"] / max(1, prof["launches"]) / (T * C)
-                                     if tr else None),
+                                     if tr else None),  # = traffic_from_profiles (the contract's field name)
                          "traffic_over_algorithmic": (tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]) if tr else None,
                          "traffic_source": (tr["round"] + " PMC passes (one-span launches), profiles/") if tr else None,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / max(1, prof["launches"]),
@@ -345,11 +455,27 @@ def main():
                                  "frac": flop * msps * 1e6 / 1e12 / world / FP32_VALU_PEAK_TFLOPS,
                                  "algorithmic_flop_per_sample": flop},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["host_fed"] = host_fed_rate(pkg, n, local_rank)
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        bank.close()
+        bank = None
+        if world == 1 and not args.no_other_configs and n == 1024 and C == 1:
+            # short legs of the other single-GPU configs, after (and outside) the headline's timed region
+            del bufs
+            torch.cuda.empty_cache()
+            oc = {}
+            oc["cfg3_frames_device"] = side_leg_frames(pkg, torch, local_rank, args.side_seconds)
+            oc["cfg5_n16384"] = side_leg_raw(pkg, torch, 16384, 26, local_rank, args.side_seconds)
+            oc["cfg3_size_n4096_raw"] = side_leg_raw(pkg, torch, 4096, 26, local_rank, args.side_seconds)
+            out["other_configs"] = oc
+            # the headline shape beyond the 256 MiB Infinity Cache (FETCH_SIZE counts fabric requests, MALL hits included)
+            out["hbm_honest"] = side_leg_raw(pkg, torch, 1024, 28, local_rank, args.side_seconds)
+        if not args.no_cpu_baseline:
+            if world == 1:
+                out["host_fed"] = host_fed_rate(pkg, n, local_rank)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, threads=max(1, min(C * world, cores)))
         print(json.dumps(out))
-    bank.close()
+    if bank is not None:
+        bank.close()
     if dist is not None:
         dist.destroy_process_group()
 

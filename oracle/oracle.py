@@ -57,6 +57,7 @@ def _declare(L):
         f("ora_cascade_new", vp, [i32, i32])
         f("ora_cascade_free", None, [vp])
         f("ora_cascade_set_avg", None, [vp, u32, u32])
+        f("ora_cascade_set_fast_fft", i32, [vp])
         f("ora_cascade_set_detrend", i32, [vp, i32])
         f("ora_cascade_process", i32, [vp, fp, sz])
         f("ora_cascade_num_stages", i32, [vp])
@@ -139,6 +140,11 @@ class PsdCascade:
 
     def set_avg(self, limit=U32_MAX, count=U32_MAX):
         self._f("ora_cascade_set_avg")(self.h, limit, count)
+
+    def set_fast_fft(self):
+        """bench.py's cpu_baseline: the radix-4 Stockham FFT whose loops gcc vectorises (same DFT, other rounding)."""
+        if self._f("ora_cascade_set_fast_fft")(self.h):
+            raise ValueError("no fast plan for this N")
 
     def process(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

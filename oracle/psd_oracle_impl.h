@@ -78,6 +78,12 @@ typedef struct {
     int n;
     REAL *tw_re, *tw_im; /* n/2 twiddles exp(-2 pi i k/n) */
     int *rev;
+    /* bench.py's cpu_baseline only (SFX(ora_cascade_set_fast_fft)): a radix-4 Stockham plan whose inner loops
+     * gcc vectorises -- a fairer stand-in for rustfft's SIMD butterflies than the scalar radix-2 above, which stays
+     * the arithmetic every parity test sees */
+    int fast, fast_stages;
+    REAL *ftw;  /* per stage: 6 arrays of n/4 (w1 re, w1 im, w2 re, w2 im, w3 re, w3 im), by butterfly index */
+    REAL *fbuf; /* 4 n: two (re, im) planar buffers */
 } SFX(ora_fft);
 
 static int SFX(fft_init)(SFX(ora_fft) * f, int n)
@@ -85,6 +91,10 @@ static int SFX(fft_init)(SFX(ora_fft) * f, int n)
     if (n < 1 || (n & (n - 1)))
         return -1;
     f->n = n;
+    f->fast = 0;
+    f->fast_stages = 0;
+    f->ftw = NULL;
+    f->fbuf = NULL;
     int h = n / 2 > 0 ? n / 2 : 1;
     f->tw_re = (REAL *)malloc(sizeof(REAL) * (size_t)h);
     f->tw_im = (REAL *)malloc(sizeof(REAL) * (size_t)h);
@@ -114,6 +124,98 @@ static void SFX(fft_free)(SFX(ora_fft) * f)
     free(f->tw_re);
     free(f->tw_im);
     free(f->rev);
+    free(f->ftw);
+    free(f->fbuf);
+}
+
+/* Radix-4 decimation-in-frequency Stockham autosort FFT on planar (re, im) arrays; a trailing radix-2 stage when
+ * log2 n is odd.  Stage with sub-length m (n, n/4, ...) and stride s = n/m: butterfly i = q + s p (p < m/4, q < s)
+ * reads x[i + k n/4], k < 4 -- contiguous in i at every stage -- and writes y[q + s (4 p + j)]. */
+static int SFX(fft_fast_plan)(SFX(ora_fft) * f)
+{
+    const int n = f->n;
+    if (n < 4)
+        return -1;
+    int st = 0;
+    for (int m = n; m >= 4; m /= 4)
+        ++st;
+    f->fast_stages = st;
+    f->ftw = (REAL *)malloc(sizeof(REAL) * (size_t)st * 6 * (size_t)(n / 4));
+    f->fbuf = (REAL *)malloc(sizeof(REAL) * 4 * (size_t)n);
+    if (!f->ftw || !f->fbuf)
+        return -1;
+    int t = 0;
+    for (int m = n, s = 1; m >= 4; m /= 4, s *= 4, ++t) {
+        REAL *w = f->ftw + (size_t)t * 6 * (size_t)(n / 4);
+        for (int i = 0; i < n / 4; ++i) {
+            const int p = i / s;
+            for (int k = 1; k <= 3; ++k) {
+                const double a = -2.0 * M_PI * (double)(k * p) / (double)m;
+                w[(2 * (k - 1)) * (n / 4) + i] = (REAL)cos(a);
+                w[(2 * (k - 1) + 1) * (n / 4) + i] = (REAL)sin(a);
+            }
+        }
+    }
+    f->fast = 1;
+    return 0;
+}
+
+static void SFX(fft_fast_forward)(const SFX(ora_fft) * f, REAL *c /* interleaved, in place */)
+{
+    const int n = f->n, q4 = n / 4;
+    REAL *restrict xr = f->fbuf, *restrict xi = f->fbuf + n, *restrict yr = f->fbuf + 2 * n, *restrict yi = f->fbuf + 3 * n;
+    for (int i = 0; i < n; ++i) {
+        xr[i] = c[2 * i];
+        xi[i] = c[2 * i + 1];
+    }
+    int t = 0, m = n, s = 1;
+    for (; m >= 4; m /= 4, s *= 4, ++t) {
+        const REAL *restrict w = f->ftw + (size_t)t * 6 * (size_t)q4;
+        const REAL *restrict w1r = w, *restrict w1i = w + q4, *restrict w2r = w + 2 * q4, *restrict w2i = w + 3 * q4,
+                   *restrict w3r = w + 4 * q4, *restrict w3i = w + 5 * q4;
+        for (int p = 0; p < m / 4; ++p) {
+            REAL *restrict o0r = yr + s * (4 * p), *restrict o0i = yi + s * (4 * p);
+            const int i0 = s * p;
+            for (int q = 0; q < s; ++q) {
+                const int i = i0 + q;
+                const REAL ar = xr[i], ai = xi[i], br = xr[i + q4], bi = xi[i + q4];
+                const REAL cr = xr[i + 2 * q4], ci = xi[i + 2 * q4], dr = xr[i + 3 * q4], di = xi[i + 3 * q4];
+                const REAL apcr = ar + cr, apci = ai + ci, amcr = ar - cr, amci = ai - ci;
+                const REAL bpdr = br + dr, bpdi = bi + di;
+                const REAL jr = -(bi - di), ji = br - dr; /* j (b - d) */
+                const REAL t1r = amcr - jr, t1i = amci - ji, t2r = apcr - bpdr, t2i = apci - bpdi;
+                const REAL t3r = amcr + jr, t3i = amci + ji;
+                o0r[q] = apcr + bpdr;
+                o0i[q] = apci + bpdi;
+                o0r[q + s] = t1r * w1r[i] - t1i * w1i[i];
+                o0i[q + s] = t1r * w1i[i] + t1i * w1r[i];
+                o0r[q + 2 * s] = t2r * w2r[i] - t2i * w2i[i];
+                o0i[q + 2 * s] = t2r * w2i[i] + t2i * w2r[i];
+                o0r[q + 3 * s] = t3r * w3r[i] - t3i * w3i[i];
+                o0i[q + 3 * s] = t3r * w3i[i] + t3i * w3r[i];
+            }
+        }
+        REAL *tr = xr, *ti = xi;
+        xr = yr;
+        xi = yi;
+        yr = tr;
+        yi = ti;
+    }
+    if (m == 2) { /* last radix-2 stage: stride s = n/2 */
+        for (int q = 0; q < s; ++q) {
+            const REAL ar = xr[q], ai = xi[q], br = xr[q + s], bi = xi[q + s];
+            yr[q] = ar + br;
+            yi[q] = ai + bi;
+            yr[q + s] = ar - br;
+            yi[q + s] = ai - bi;
+        }
+        xr = yr;
+        xi = yi;
+    }
+    for (int i = 0; i < n; ++i) {
+        c[2 * i] = xr[i];
+        c[2 * i + 1] = xi[i];
+    }
 }
 
 /* in-place on interleaved (re, im) pairs */
@@ -229,12 +331,19 @@ static void SFX(hbf2_block)(SFX(ora_hbf2) * h, const REAL *x, int k, REAL *y, RE
         e[m - 1 + j] = x[2 * j];
         o[2 * m - 1 + j] = x[2 * j + 1];
     }
-    for (int j = 0; j < k; ++j) {
-        REAL acc = 0;
-        for (int i = 0; i < m; ++i)
-            acc += (o[j + i] + o[j + 2 * m - 1 - i]) * h->taps[i];
-        y[j] = e[j] + acc;
+    /* per output: acc = 0; acc += (old + new) * tap for i = 0..M-1 in order; y = even + acc -- written with the tap
+     * loop outside so that the compiler vectorises over the outputs (the same operations in the same order for
+     * every output, hence the same bits) */
+    for (int j = 0; j < k; ++j)
+        y[j] = 0;
+    for (int i = 0; i < m; ++i) {
+        const REAL t = h->taps[i];
+        const REAL *restrict oa = o + i, *restrict ob = o + 2 * m - 1 - i;
+        for (int j = 0; j < k; ++j)
+            y[j] += (oa[j] + ob[j]) * t;
     }
+    for (int j = 0; j < k; ++j)
+        y[j] = e[j] + y[j];
     memcpy(h->even, e + k, sizeof(REAL) * (size_t)(m - 1));
     memcpy(h->odd, o + k, sizeof(REAL) * (size_t)(2 * m - 1));
 }
@@ -352,7 +461,10 @@ static long SFX(psd_process)(SFX(ora_psd) * s, const REAL *x, size_t xlen, REAL 
         /* detrend and window :211, fft :213 */
         if (SFX(detrend_apply)(s->detrend, s->buf, s->win, s->c))
             return -1;
-        SFX(fft_forward)(s->fft, s->c);
+        if (s->fft->fast)
+            SFX(fft_fast_forward)(s->fft, s->c);
+        else
+            SFX(fft_forward)(s->fft, s->c);
 
         const int is_first = s->count == 0; /* :215 */
 
@@ -497,6 +609,9 @@ void SFX(ora_cascade_free)(SFX(ora_cascade) * c)
     free(c->xin);
     free(c);
 }
+
+/* cpu_baseline only: switch this cascade's FFT to the vectorisable radix-4 plan (same DFT, other rounding) */
+int SFX(ora_cascade_set_fast_fft)(SFX(ora_cascade) * c) { return c->fft.fast ? 0 : SFX(fft_fast_plan)(&c->fft); }
 
 void SFX(ora_cascade_set_avg)(SFX(ora_cascade) * c, uint32_t limit, uint32_t count)
 { /* :431-436 */

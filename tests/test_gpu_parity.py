@@ -55,13 +55,14 @@ def check_against_oracle(pkg, ora, gpu, x_chunks, n, detrend="none", avg=None, w
     for opts in (pkg.MergeOpts(), pkg.MergeOpts(True, 0, True), pkg.MergeOpts(False, 2, False)):
         p, br = gpu.psd(channel, opts)
         pr, brr, cbr = ref.psd(opts.keep_overlap, opts.min_count, opts.keep_transition_band)
+        p32 = r32.psd(opts.keep_overlap, opts.min_count, opts.keep_transition_band)[0] if r32 is not None else None
         assert len(br) == len(brr)
         for b, r in zip(br, brr):
             assert (b.start, b.include, b.count, b.avg, b.bins.start, b.bins.stop, b.fft_size,
                     b.decimation, b.pending, b.processed) == (
                 r["start"], bool(r["include"]), r["count"], r["avg"], r["bins_start"], r["bins_end"],
                 r["fft_size"], r["decimation"], r["pending"], r["processed"]), f"{what}: break {b} vs {r}"
-        assert_psd_close(p, pr, f"{what} merged psd {opts}")
+        assert_psd_close(p, pr, f"{what} merged psd {opts}", ref_f32=p32 if p32 is not None and p32.shape == pr.shape else None)
         for b in br:  # the merged PSD is the stages' bins scaled: the pure bound holds slice by slice
             if b.include and is_pure(b.count):
                 sl = slice(b.start, b.start + len(b.bins))
@@ -255,21 +256,24 @@ def test_settings_change_midstream(pkg, ora, gpu_required):
     n = 128
     x = make_signal(pkg, 50000, seed=21, dc=2.0)
     g = pkg.PsdCascadeBank(n)
-    ref = ora.PsdCascade(n, "f64")
+    ref, r32 = ora.PsdCascade(n, "f64"), ora.PsdCascade(n, "f32")
     g.process(0, x[:17777])
-    ref.process(x[:17777])
+    for o in (ref, r32):
+        o.process(x[:17777])
+        o.set_detrend("mean")
     g.set_detrend(pkg.Detrend.MEAN)
-    ref.set_detrend("mean")
     g.process(0, x[17777:30000])
-    ref.process(x[17777:30000])
+    for o in (ref, r32):
+        o.process(x[17777:30000])
+        o.set_avg(20, 20)
     g.set_avg(pkg.AvgOpts(20, 20))
-    ref.set_avg(20, 20)
     g.process(0, x[30000:])
-    ref.process(x[30000:])
+    for o in (ref, r32):
+        o.process(x[30000:])
     for k in range(ref.num_stages):
         assert g.stage_info(0, k) == ref.stage_info(k)
         if ref.stage_info(k)["count"]:
-            assert_psd_close(g.stage_spectrum(0, k), ref.stage_spectrum(k), f"stage {k}")
+            assert_psd_close(g.stage_spectrum(0, k), ref.stage_spectrum(k), f"settings change, stage {k}", ref_f32=r32.stage_spectrum(k))
     g.close()
 
 
@@ -1004,7 +1008,8 @@ def test_single_stage_finite_averaging_and_device_io(pkg, ora, gpu_required):
     x = make_signal(pkg, (1 << 20) + 40, seed=77, tone=0.2)
     s = pkg.Psd(n)
     s.set_avg(25)
-    ref = ora.Psd(n, "f64", avg=25)
+    ref, r32 = ora.Psd(n, "f64", avg=25), ora.Psd(n, "f32", avg=25)
+    r32.process(x)
     d = torch.from_numpy(x).cuda()
     y = torch.zeros(x.size // 8 + n // 8, dtype=torch.float32, device="cuda")
     m = s.process_device(d.data_ptr(), x.size, y.data_ptr(), y.numel())
@@ -1012,7 +1017,7 @@ def test_single_stage_finite_averaging_and_device_io(pkg, ora, gpu_required):
     assert m == yr.size
     assert np.max(np.abs(y[:m].cpu().numpy() - yr)) <= 4e-6 * np.max(np.abs(yr))
     assert s.count() == ref.count() == 26
-    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<1024> avg 25")
+    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<1024> avg 25", ref_f32=r32.spectrum())
     s.close()
 
 
@@ -1231,4 +1236,26 @@ def test_sixty_four_channel_bank(pkg, ora, gpu_required):
         assert np.array_equal(merged[c][0], p)
         plan = pkg.plan_counts(n, lens[c])
         assert [b.count for b in reversed(br)] == [segs for _, segs, _ in plan]
+    g.close()
+
+
+@pytest.mark.timeout(600)
+def test_n16384_deep_single_pass_vs_oracle(pkg, ora, gpu_required):
+    """Config 5's kernel (bigfused_kernel<16384>) deeper than the size sweep reaches: ONE device-resident pass of 2^27
+    samples (five stages with spectra: 16383 / 2046 / 254 / 30 / 2 segments) against the f64 oracle on the same samples -- pure 1e-5 on every stage with at
+    least four averages, counters exact.  (Ten stages need 2.4e12 samples: only properties can follow that far,
+    test_config5_ten_stages.)"""
+    import torch
+    n, total = 16384, 1 << 27
+    d = torch.empty(total, dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), total, seed=0x7654321)
+    x = pkg.noise_host(total, seed=0x7654321)
+    g = pkg.PsdCascadeBank(n)
+    half = total // 2 + 8 * 1031  # two uneven in-place spans
+    g.process_device(0, d.data_ptr(), half)
+    g.process_device(0, d.data_ptr() + 4 * half, total - half)
+    w = check_against_oracle(pkg, ora, g, [x], n, what="N=16384, 2^27 samples", pure_min_count=4, justify=False)
+    counts = [g.stage_info(0, k)["count"] for k in range(g.num_stages(0))]
+    assert counts[:5] == [16383, 2046, 254, 30, 2] == [s for _, s, _ in pkg.plan_counts(n, total)][:5]
+    print(f"N=16384 x 2^27 samples vs the f64 oracle: stages {counts}, worst relative error {w:.3g}")
     g.close()

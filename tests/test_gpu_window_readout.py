@@ -187,11 +187,12 @@ def test_one_process_two_handles_gather_without_a_collective(pkg, ora, gpu_requi
     cur = torch.cuda.current_device()
     for g, (r, c) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
         p, br = pkg.unpack_stitch(recs[r], c)
-        one = ora.PsdCascade(n, "f64")
+        one, o32 = ora.PsdCascade(n, "f64"), ora.PsdCascade(n, "f32")
         one.process(xs[g])
+        o32.process(xs[g])
         pr, brr, _ = one.psd()
         assert [b.count for b in br] == [b["count"] for b in brr]
-        assert_psd_close(p, pr, f"global channel {g}", pure=False)
+        assert_psd_close(p, pr, f"global channel {g}", ref_f32=o32.psd()[0])
     assert torch.cuda.current_device() == cur  # every ABI call restores the caller's device
     h0.close()
     h1.close()

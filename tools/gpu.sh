@@ -29,7 +29,7 @@ print(sys.argv[1], "| MS/s", round(d["value"]), "ms/step", round(d["ms_per_step"
       d["config"]["stages"], "stages")'
 line() { # line "<bench args>" [extra args]
   local a="$1"; shift
-  timeout -k 10 400 python bench.py $a "$@" --no-cpu-baseline > "$out/bench.log" 2>&1; local rc=$?
+  timeout -k 10 400 python bench.py $a "$@" --no-cpu-baseline --no-other-configs > "$out/bench.log" 2>&1; local rc=$?
   grep '^{' "$out/bench.log" | python -c "$condense" "$a" || { echo "$a rc=$rc"; tail -5 "$out/bench.log"; }
   grep '^{' "$out/bench.log" >> "$out/lines.jsonl"
   return $rc
@@ -38,7 +38,7 @@ prof() { # prof <subdir> <prefix> <rocprof flags...> -- <bench args>
   local o="$R/gpurun_out/$1" p=$2; shift 2
   local flags=(); while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
   mkdir -p "$o"
-  (cd /tmp && TMPDIR=/tmp timeout -k 10 700 rocprofv3 "${flags[@]}" --output-format csv -d "$o" -o "$p" -- python3 "$R/bench.py" "$@" --no-cpu-baseline > "$o/${p}_bench.log" 2>&1)
+  (cd /tmp && TMPDIR=/tmp timeout -k 10 700 rocprofv3 "${flags[@]}" --output-format csv -d "$o" -o "$p" -- python3 "$R/bench.py" "$@" --no-cpu-baseline --no-other-configs > "$o/${p}_bench.log" 2>&1)
 }
 case $mode in
 tests)
