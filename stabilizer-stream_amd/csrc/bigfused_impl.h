@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include "fft_block.h"
+#include "frames.h"
 #include "fused_common.h"
 
 namespace psdk {
@@ -45,7 +46,12 @@ struct BigGeo : FusedDec<N> {
 
 // DETREND / EWMA as in fused.hip.  Built for four wavefronts per SIMD (two at N = 16384, whose one
 // workgroup per CU is all the LDS holds).
-template <int N, int DETREND, bool EWMA>
+// FRAMES: the launch may hold jobs whose stream is read in place from AdcDac frames (job.fspan >= 0; psdc_process_adcdac_
+// frames_device): a lane's four consecutive samples are one 8-byte buffer load of wire words (src/de/data.rs:13), kept raw in
+// the register group until the loads have landed and converted there (i16 -> f32 x LSB, DAC words offset binary, :28-35,
+// :64,:75) -- the four f32 streams of the traces never exist in memory.  Built as separate kernels: the f32-only launches
+// keep their instruction stream and registers.
+template <int N, int DETREND, bool EWMA, bool FRAMES = false>
 __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_kernel(const FusedBatch batch,
                                                                          const float *__restrict__ win,
                                                                          const cf *__restrict__ tw0g,
@@ -67,11 +73,34 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         s_twb[i] = {cs, sn};
     }
 
+    int bid = blockIdx.x;
+    if constexpr (FRAMES) {
+        // the four traces of a frame span read the SAME bytes: deal the workgroups of a group so that the four with one
+        // run index w get physical ids 8 apart -- one XCD under the observed round-robin placement (speed only): its L2
+        // serves three of the four reads and the frames cross the fabric once
+        for (int g = 0; g < batch.n_fgroups; ++g) {
+            const int b0 = batch.fg_begin[g], nb = batch.fg_nb[g];
+            if (bid >= b0 && bid < b0 + 4 * nb) {
+                const int p = bid - b0, full = (nb >> 3) * 32;
+                int c, w;
+                if (p < full) {
+                    c = (p >> 3) & 3;
+                    w = (p >> 5) * 8 + (p & 7);
+                } else {
+                    const int rem = nb & 7, q = p - full;
+                    c = q / rem;
+                    w = (nb & ~7) + q % rem;
+                }
+                bid = b0 + c * nb + w;
+                break;
+            }
+        }
+    }
     int ji = 0;
-    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
+    while (ji + 1 < batch.njobs && bid >= batch.jobs[ji + 1].block_begin)
         ++ji;
     const FusedJob &job = batch.jobs[ji];
-    const int wb = blockIdx.x - job.block_begin;
+    const int wb = bid - job.block_begin;
     const int npairs = job.npairs, run = job.run;
 
     cf *frame = s_frame;
@@ -93,19 +122,65 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     // this workgroup's run: pairs [p0, p0 + run) of the job (cut by npairs)
     const int p0 = wb * run;
     const int p1 = min(npairs, p0 + run);
+    // the stream of this job: an f32 array (cp: this thread's piece of chunk p0, in float4 units) or, in a FRAMES launch,
+    // trace job.fch of a frame span (sp: the sample index of the same piece within the span)
+    const bool fr = FRAMES && job.fspan >= 0;
+    const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
+    const unsigned ch_off = fr ? (unsigned)job.fch * 16u : 0u;
+    const unsigned dac_flip = (fr && job.fch >= 2) ? 0x80008000u : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(fsp.frames), 0, fr ? (int)min(fsp.bytes, 0x7FFFFFFFull) : 0, 0x00020000);
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tp;
+    unsigned sp = job.s_off + (unsigned)p0 * N + 4u * tp;
+    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words in .x / .y
+    auto piece = [&](const float4 *c, unsigned s, int k) -> float4 {
+        if constexpr (FRAMES) {
+            if (fr) {
+                const unsigned si = s + 4u * (unsigned)k;
+                const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const u2v r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                return make_float4(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), 0.0f, 0.0f);
+            }
+        }
+        return c[k];
+    };
+    // raw wire words -> volts, in place (a no-op for f32 jobs)
+    auto volts = [&](float4 &g) {
+        if constexpr (FRAMES) {
+            if (fr) {
+                const unsigned a = __builtin_bit_cast(unsigned, g.x) ^ dac_flip, b = __builtin_bit_cast(unsigned, g.y) ^ dac_flip;
+                const float lsb = adcdac_lsb();
+                g.x = (float)(short)(unsigned short)(a & 0xffffu) * lsb;
+                g.y = (float)(short)(unsigned short)(a >> 16) * lsb;
+                g.z = (float)(short)(unsigned short)(b & 0xffffu) * lsb;
+                g.w = (float)(short)(unsigned short)(b >> 16) * lsb;
+            }
+        }
+    };
     const float4 *safe = cp; // look-ahead target once nothing is left to look ahead to
+    unsigned safe_s = sp;
     // register groups of a lane: two float4 each (see pair_step)
     float4 ga[VT][2], gb[VT][2], gc[VT][2];
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
         const float4 *c = cp + THREADS * v;
-        ga[v][0] = c[0];
-        ga[v][1] = c[TEAM];
-        gb[v][0] = c[2 * TEAM];
-        gb[v][1] = c[3 * TEAM];
-        gc[v][0] = c[N / 4];
-        gc[v][1] = c[N / 4 + TEAM];
+        const unsigned s = sp + 4u * THREADS * v;
+        ga[v][0] = piece(c, s, 0);
+        ga[v][1] = piece(c, s, TEAM);
+        gb[v][0] = piece(c, s, 2 * TEAM);
+        gb[v][1] = piece(c, s, 3 * TEAM);
+        gc[v][0] = piece(c, s, N / 4);
+        gc[v][1] = piece(c, s, N / 4 + TEAM);
+    }
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        volts(ga[v][0]);
+        volts(ga[v][1]);
+        volts(gb[v][0]);
+        volts(gb[v][1]);
+        volts(gc[v][0]);
+        volts(gc[v][1]);
     }
 
     // ---- warm-up: filter state at the first new sample of the run (hop >= 1024 > 288, so the
@@ -114,8 +189,17 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         const float *xn = job.src + (size_t)p0 * N + N / 2;
         for (int r = tp; r < G::WX / 2; r += THREADS) {
             const int i0 = 2 * r - G::WX;
-            sf[G::WXE + r] = xn[i0];
-            sf[G::WXO + r] = xn[i0 + 1];
+            float e, o;
+            if (fr) {
+                const unsigned long long si = (unsigned long long)job.s_off + (unsigned long long)p0 * N + N / 2 + i0;
+                e = frame_sample(fsp, job.fch, si);
+                o = frame_sample(fsp, job.fch, si + 1);
+            } else {
+                e = xn[i0];
+                o = xn[i0 + 1];
+            }
+            sf[G::WXE + r] = e;
+            sf[G::WXO + r] = o;
         }
         __syncthreads();
         for (int u = tp; u < G::WA / 2; u += THREADS) {
@@ -184,8 +268,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     };
 
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
-    auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, bool more,
-                         float *o, int p) {
+    auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, unsigned snext,
+                         bool more, float *o, int p) {
         // The window and twiddle tables are the same for every pair, and left alone the compiler hoists the
         // loads and keeps all of a lane's entries (8 + 30 + 16 registers) live across the whole run -- which pins
         // the kernels to two wavefronts per SIMD (or spills, with two lanes per thread).  The table pointers are
@@ -378,14 +462,17 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             for (int r = 0; r < VT; ++r)
                 *reinterpret_cast<f2 *>(o + 2 * (tp + THREADS * r)) = yc[r];
             const float4 *src = more ? cnext : safe;
+            const unsigned ssrc = more ? snext : safe_s;
             safe = src;
+            safe_s = ssrc;
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
                 const float4 *c = src + THREADS * v;
-                up[v][0] = c[2 * TEAM];
-                up[v][1] = c[3 * TEAM];
-                lo[v][0] = c[N / 4];
-                lo[v][1] = c[N / 4 + TEAM];
+                const unsigned s = ssrc + 4u * THREADS * v;
+                up[v][0] = piece(c, s, 2 * TEAM);
+                up[v][1] = piece(c, s, 3 * TEAM);
+                lo[v][0] = piece(c, s, N / 4);
+                lo[v][1] = piece(c, s, N / 4 + TEAM);
             }
         }
         PSDK_FFT_BARRIER();
@@ -406,18 +493,29 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 q[v][s] = fmaf(vv[v][s].re, vv[v][s].re, fmaf(vv[v][s].im, vv[v][s].im, q[v][s]));
             lane_fence();
         }
+        if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                volts(up[v][0]);
+                volts(up[v][1]);
+                volts(lo[v][0]);
+                volts(lo[v][1]);
+            }
+        }
         __syncthreads(); // next pair's decimator writes the frame
     };
 
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
         for (int p = p0; p < p1; p += 2) {
-            pair_step(ga, gb, gc, cp + N / 4, p + 1 < p1, o, p);
+            pair_step(ga, gb, gc, cp + N / 4, sp + N, p + 1 < p1, o, p);
             cp += N / 4;
+            sp += N;
             o += N / 8;
             if (p + 1 < p1) {
-                pair_step(gc, gb, ga, cp + N / 4, p + 2 < p1, o, p + 1);
+                pair_step(gc, gb, ga, cp + N / 4, sp + N, p + 2 < p1, o, p + 1);
                 cp += N / 4;
+                sp += N;
                 o += N / 8;
             }
         }
@@ -439,7 +537,11 @@ hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw
     const dim3 grid(b.nblocks), block(BigGeo<N>::THREADS);
 #define PSDK_BIG_CASE(D)                                                                          \
     case D:                                                                                       \
-        if (b.any_ewma)                                                                           \
+        if (b.any_frames && b.any_ewma)                                                           \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
+        else if (b.any_frames)                                                                    \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
+        else if (b.any_ewma)                                                                      \
             hipExtLaunchKernelGGL((bigfused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
         else                                                                                      \
             hipExtLaunchKernelGGL((bigfused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \

@@ -513,6 +513,8 @@ bool fused_supported(int n)
     return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384;
 }
 
+bool fused_frames_supported(int n) { return n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+
 int fused_pairs_per_block(int n, int run)
 {
     switch (n) {
@@ -591,6 +593,8 @@ void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa)
 template <int N>
 static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
+    if (b.any_frames)
+        return hipErrorInvalidValue; // the team-level kernels read f32 streams only (fused_frames_supported)
     static_assert(FusedGeo<N>::LDS_BYTES * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES) <= 163840,
                   "the workgroups of a CU (two of eight waves by default) share its 160 KiB of LDS");
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);

@@ -15,6 +15,22 @@ namespace psdk {
 #endif
 constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
 
+// AdcDac frames resident in device memory as a stage-0 sample source (src/de/data.rs:11-82): the four traces of a run
+// of whole frames.  Sample i of trace ch: cell = i >> 3 (one 16-byte (batch, channel) cell = 8 i16 samples, src/de/data.rs:13),
+// frame = cell / batches, batch = cell % batches, at frames + frame * frame_size + 8 + batch * 64 + ch * 16 + (i & 7) * 2;
+// ADC words are i16, DAC words offset binary (i16.wrapping_add(i16::MIN), :64,:75), both times 4.096 * 2.5 / 32768 (:28-35).
+// Jobs name a span by its index in their batch's table (fspan >= 0) and say where in the span they start (s_off, samples).
+struct FrameSpan {
+    const uint8_t *frames;
+    unsigned long long bytes; // n_frames * frame_size (the bound of the buffer descriptor the fused kernels read through)
+    unsigned frame_size;
+    unsigned batches;         // 1 ... 255
+    unsigned magic;           // ceil(2^32 / batches): cell / batches == umulhi(cell, magic) for cell < 2^24 (batches >= 2)
+    unsigned pad;
+};
+constexpr int MAX_FSPANS = 16;                      // frame spans per launch (= spans of one channel in one round)
+constexpr unsigned long long FSPAN_MAX_SAMPLES = 1ull << 26; // per trace and span: cells stay below 2^23
+
 // One span of consecutive segments of one (channel, stage) stream.
 struct SegJob {
     const float *src;    // sample with absolute stream index i is src[i - src_base]
@@ -30,6 +46,9 @@ struct SegJob {
     int nb;              // EWMA: steps in the whole (channel, stage) batch
     int is_m1;           // EWMA: i_s - 1
     int ewma;            // 0: plain sum (all weights 1)
+    int fspan = -1;      // >= 0: src is trace fch of frame span fspans[fspan]; sample i of the stream is sample
+    int fch = 0;         //       (i - src_base) + s_off of that trace (src unused)
+    unsigned s_off = 0;
 };
 
 struct WelchBatch {
@@ -37,6 +56,7 @@ struct WelchBatch {
     int nblocks; // grid size
     int hop;
     int detrend;
+    FrameSpan fspans[MAX_FSPANS];
     SegJob jobs[MAX_JOBS];
 };
 
@@ -49,12 +69,15 @@ struct DecJob {
     long long dst_base;
     int nout;
     int tile_begin;
+    int fspan = -1, fch = 0; // as in SegJob
+    unsigned s_off = 0;
 };
 
 struct DecBatch {
     int njobs;
     int ntiles;
     int drain;
+    FrameSpan fspans[MAX_FSPANS];
     DecJob jobs[MAX_JOBS];
 };
 
@@ -93,6 +116,8 @@ struct FusedJob {
     int nb;
     int is_m1;
     int ewma;
+    int fspan = -1, fch = 0; // as in SegJob: src = sample s_off of trace fch of fspans[fspan] (s_off a multiple of 4)
+    unsigned s_off = 0;
 };
 
 struct FusedBatch {
@@ -100,6 +125,13 @@ struct FusedBatch {
     int nblocks;
     int detrend;  // Detrend kind 0..3 for every job of the launch
     int any_ewma; // some job has finite averaging weights
+    int any_frames; // some job reads AdcDac frames (the kernels built with the frame loads run this launch)
+    // frame jobs come first in the launch, four by four (the traces of one span, equal workgroup counts): group g
+    // = workgroups [fg_begin[g], fg_begin[g] + 4 fg_nb[g]); the kernel deals a group's workgroups so that the four
+    // that read the same frames sit on one XCD (they share its L2: the frame bytes cross the fabric once, not four times)
+    int n_fgroups;
+    int fg_begin[MAX_FSPANS], fg_nb[MAX_FSPANS];
+    FrameSpan fspans[MAX_FSPANS];
     FusedJob jobs[MAX_JOBS];
 };
 
@@ -121,10 +153,13 @@ struct TailJob {
     const float *src;
     float *dst;
     int count;
+    int fspan = -1, fch = 0; // >= 0: decode samples s_off ... of trace fch of fspans[fspan] instead of copying src
+    unsigned s_off = 0;
 };
 
 struct TailBatch {
     int njobs;
+    FrameSpan fspans[MAX_FSPANS];
     TailJob jobs[MAX_JOBS];
 };
 
@@ -136,6 +171,7 @@ constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 bool welch_supported(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
 bool fused_supported(int n);                 // N = 256 ... 16384
+bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
 int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
 // twiddle tables in global memory for the workgroup-level kernels (N >= 2048); empty otherwise
@@ -154,11 +190,12 @@ hipError_t launch_copy_out(float *h_dst, const float *d_src, size_t count, hipSt
 hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,
                          float *dst0, float *dst1, float *dst2, float *dst3, hipStream_t s);
 
-// device-resident frames (out: device memory, zeroed): header checks of every frame (out[0] <- max ~(index << 2 | code)
-// over the bad ones) and the
-// Loss counters over the first n (out[1] += batches, out[2] += sequence gaps, out[3] = first seq | next seq << 32)
-hipError_t launch_adcdac_scan(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok,
-                              unsigned long long *out, hipStream_t s);
-hipError_t launch_adcdac_loss(const uint8_t *frames, size_t frame_size, size_t n, unsigned long long *out, hipStream_t s);
+// device-resident frames: header checks of every frame (check != 0) and the Loss counters over the first n_loss, in ONE
+// launch; the four result words land in host_out (pinned host memory) when the stream has run the kernel: host_out[0] =
+// max ~(index << 2 | code) over the bad frames (0: none), [1] batches received, [2] sequence gaps, [3] first seq | next seq
+// << 32.  acc: 5 device words, zero before the first call (the kernel leaves them zero).
+constexpr int FRAME_RESERVE_BLOCKS = 8; // workgroup slots a frame round leaves free for it (it runs beside the fused launch)
+hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok, int check,
+                                 size_t n_loss, unsigned long long *acc, unsigned long long *host_out, hipStream_t s);
 
 } // namespace psdk

@@ -14,6 +14,7 @@
 // No MFMA: the path is FP32-VALU / LDS bound.  64-wide
 // wavefronts throughout; LDS frames are exchanged with 8-byte accesses.
 #include "kernels.h"
+#include "frames.h"
 #include "hbf_taps.h"
 
 namespace psdk {
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
         const int p = p0 + team;
         const int la = seg_lo + 2 * p; // local segment index of the "real" lane
         const bool act_a = la < seg_hi, act_b = la + 1 < seg_hi;
-        const float *xa = job.src + ((job.seg0 + la) * (long long)hop - job.src_base);
-        const float *xb = xa + hop;
+        // sample j of segment a / b: from the f32 stream, or decoded from AdcDac frames (a stage-0 span read in place)
+        const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
+        const bool fr = job.fspan >= 0;
+        const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
+        auto xa = [&](int j) { return fr ? frame_sample(fsp, job.fch, (unsigned long long)(ofs_a + job.s_off + j)) : job.src[ofs_a + j]; };
+        auto xb = [&](int j) { return xa(j + hop); };
 
         float ra[E], rb[E];
 #pragma unroll
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
 #pragma unroll
             for (int m = 0; m < P0::R; ++m) {
                 const int nidx = P0::elem(t, i, m);
-                ra[i * P0::R + m] = act_a ? xa[nidx] : 0.0f;
-                rb[i * P0::R + m] = act_b ? xb[nidx] : 0.0f;
+                ra[i * P0::R + m] = act_a ? xa(nidx) : 0.0f;
+                rb[i * P0::R + m] = act_b ? xb(nidx) : 0.0f;
             }
 
         // Detrend (src/psd.rs:75-113) as (x - o) - (m + n s): o is a sample of the segment, so the
@@ -119,16 +124,16 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
         float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
         slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
         if (detrend == 1) { // Midpoint :87-93
-            oa = act_a ? xa[N / 2] : 0.0f;
-            ob = act_b ? xb[N / 2] : 0.0f;
+            oa = act_a ? xa(N / 2) : 0.0f;
+            ob = act_b ? xb(N / 2) : 0.0f;
         } else if (detrend == 2) { // Span :94-102 (ramp evaluated as o0 + n*slope)
             if (act_a) {
-                oa = xa[0];
-                sa = span_slope(oa, xa[N - 1], N);
+                oa = xa(0);
+                sa = span_slope(oa, xa(N - 1), N);
             }
             if (act_b) {
-                ob = xb[0];
-                sb = span_slope(ob, xb[N - 1], N);
+                ob = xb(0);
+                sb = span_slope(ob, xb(N - 1), N);
             }
         } else if (detrend == 3) { // Mean :103-109 in two steps: o = f32 mean of the samples, m = mean of x - o
             // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
@@ -296,9 +301,15 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
         const long long i0 = x0 + 2 * r;
         float e = 0.0f, o = 0.0f;
         if (i0 >= 0 && i0 + 1 < x_end) {
-            const float *p = job.src + (i0 - job.src_base);
-            e = p[0];
-            o = p[1];
+            if (job.fspan >= 0) { // AdcDac frames read in place
+                const unsigned long long si = (unsigned long long)(i0 - job.src_base + job.s_off);
+                e = frame_sample(batch.fspans[job.fspan], job.fch, si);
+                o = frame_sample(batch.fspans[job.fspan], job.fch, si + 1);
+            } else {
+                const float *p = job.src + (i0 - job.src_base);
+                e = p[0];
+                o = p[1];
+            }
         }
         xe[r] = e;
         xo[r] = o;
@@ -370,6 +381,12 @@ __global__ __launch_bounds__(RED_BINS *RED_SLICES) void post_kernel(const RedBat
         return;
     }
     const TailJob &job = tail.jobs[blockIdx.x - nred];
+    if (job.fspan >= 0) { // a seam or a carried tail whose samples still sit in AdcDac frames: decoded on the way
+        const FrameSpan &fs = tail.fspans[job.fspan];
+        for (int i = threadIdx.x; i < job.count; i += RED_BINS * RED_SLICES)
+            job.dst[i] = frame_sample(fs, job.fch, (unsigned long long)job.s_off + (unsigned long long)i);
+        return;
+    }
     for (int i = threadIdx.x; i < job.count; i += RED_BINS * RED_SLICES)
         job.dst[i] = job.src[i];
 }
@@ -421,60 +438,75 @@ __global__ __launch_bounds__(256) void adcdac_kernel(const uint8_t *__restrict__
     }
 }
 
-// Device-resident frames: Header::parse (src/de/frame.rs:25-37) + the AdcDac size checks (src/de/data.rs:22-25) of
-// every frame, in the reference's order; out[0] <- max over the bad frames of ~(index << 2 | code) (code 1
-// InvalidHeader, 2 UnknownFormat, 3 PayloadSize / batches mismatch), i.e. the FIRST bad frame; 0 if all are good.
-__global__ __launch_bounds__(256) void adcdac_scan_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames,
-                                                          int batches, int payload_ok, unsigned long long *out)
-{
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (size_t)gridDim.x * 256) {
-        const uint8_t *p = frames + f * frame_size;
-        int code = 0;
-        if (p[0] != 0x7b || p[1] != 0x05)
-            code = 1;
-        else if (p[2] != 1)
-            code = 2;
-        else if (!payload_ok || (int)p[3] != batches)
-            code = 3;
-        if (code)
-            atomicMax(out, ~(((unsigned long long)f << 2) | (unsigned long long)code));
-    }
-}
-
-// Loss::update (src/loss.rs:11-26) over frames [0, n): out[1] += batches, out[2] += the u32 sequence gaps between
-// consecutive frames (wrapping_sub), out[3] <- seq of frame 0 (low half) and seq + batches of the last (high half).
-__global__ __launch_bounds__(256) void adcdac_loss_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n,
-                                                          unsigned long long *out)
+// Device-resident frames, one pass: Header::parse (src/de/frame.rs:25-37) + the AdcDac size checks (src/de/data.rs:22-25) of
+// every frame, in the reference's order -- acc[0] <- max over the bad frames of ~(index << 2 | code) (code 1 InvalidHeader,
+// 2 UnknownFormat, 3 PayloadSize / batches mismatch), i.e. the FIRST bad frame; 0 if all are good -- and Loss::update
+// (src/loss.rs:11-26) over frames [0, n_loss): acc[1] += batches, acc[2] += the u32 sequence gaps between consecutive frames
+// (wrapping_sub), acc[3] <- seq of frame 0 (low half) | seq + batches of the last (high half).  The workgroup that
+// finishes last (acc[4]: arrival ticket) copies the four words to `host_out` (pinned host memory) and zeroes acc for the
+// next call: one launch, no memset, no copy kernel -- the call sits on a side stream and the host waits for it alone.
+__global__ __launch_bounds__(256) void adcdac_verdict_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames,
+                                                             int batches, int payload_ok, int check, size_t n_loss,
+                                                             unsigned long long *acc, unsigned long long *host_out)
 {
     auto seq_of = [&](size_t f) {
         const uint8_t *p = frames + f * frame_size;
         return (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
     };
-    unsigned long long rec = 0, drop = 0;
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n; f += (size_t)gridDim.x * 256) {
-        const uint32_t b = frames[f * frame_size + 3];
-        rec += b;
-        if (f > 0)
-            drop += (uint32_t)(seq_of(f) - (seq_of(f - 1) + (uint32_t)frames[(f - 1) * frame_size + 3]));
-        if (f == 0)
-            atomicOr(out + 3, (unsigned long long)seq_of(0));
-        if (f == n - 1)
-            atomicOr(out + 3, (unsigned long long)(uint32_t)(seq_of(f) + b) << 32);
+    unsigned long long rec = 0, drop = 0, bad = 0;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (size_t)gridDim.x * 256) {
+        const uint8_t *p = frames + f * frame_size;
+        if (check) {
+            int code = 0;
+            if (p[0] != 0x7b || p[1] != 0x05)
+                code = 1;
+            else if (p[2] != 1)
+                code = 2;
+            else if (!payload_ok || (int)p[3] != batches)
+                code = 3;
+            if (code) {
+                const unsigned long long key = ~(((unsigned long long)f << 2) | (unsigned long long)code);
+                bad = key > bad ? key : bad;
+            }
+        }
+        if (f < n_loss) {
+            const uint32_t b = p[3];
+            rec += b;
+            if (f > 0)
+                drop += (uint32_t)(seq_of(f) - (seq_of(f - 1) + (uint32_t)frames[(f - 1) * frame_size + 3]));
+            if (f == 0)
+                atomicOr(acc + 3, (unsigned long long)seq_of(0));
+            if (f == n_loss - 1)
+                atomicOr(acc + 3, (unsigned long long)(uint32_t)(seq_of(f) + b) << 32);
+        }
     }
-    __shared__ unsigned long long s_rec[256], s_drop[256];
+    __shared__ unsigned long long s_rec[256], s_drop[256], s_bad[256];
+    __shared__ int s_last;
     s_rec[threadIdx.x] = rec;
     s_drop[threadIdx.x] = drop;
+    s_bad[threadIdx.x] = bad;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             s_rec[threadIdx.x] += s_rec[threadIdx.x + o];
             s_drop[threadIdx.x] += s_drop[threadIdx.x + o];
+            s_bad[threadIdx.x] = s_bad[threadIdx.x] > s_bad[threadIdx.x + o] ? s_bad[threadIdx.x] : s_bad[threadIdx.x + o];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        atomicAdd(out + 1, s_rec[0]);
-        atomicAdd(out + 2, s_drop[0]);
+        if (s_bad[0])
+            atomicMax(acc, s_bad[0]);
+        atomicAdd(acc + 1, s_rec[0]);
+        atomicAdd(acc + 2, s_drop[0]);
+        __threadfence(); // this workgroup's sums are visible device-wide before its ticket is
+        s_last = atomicAdd(acc + 4, 1ull) + 1 == (unsigned long long)gridDim.x;
+        if (s_last) { // every other workgroup's atomics came before its ticket: read them back with atomics too
+            for (int i = 0; i < 4; ++i)
+                host_out[i] = atomicExch(acc + i, 0ull);
+            atomicExch(acc + 4, 0ull);
+            __threadfence_system();
+        }
     }
 }
 
@@ -482,22 +514,15 @@ __global__ __launch_bounds__(256) void adcdac_loss_kernel(const uint8_t *__restr
 // launchers
 // ---------------------------------------------------------------------------
 
-hipError_t launch_adcdac_scan(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok,
-                              unsigned long long *out, hipStream_t s)
+hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok, int check,
+                                 size_t n_loss, unsigned long long *acc, unsigned long long *host_out, hipStream_t s)
 {
     if (n_frames == 0)
         return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n_frames + 255) / 256);
-    hipLaunchKernelGGL(adcdac_scan_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, payload_ok, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_adcdac_loss(const uint8_t *frames, size_t frame_size, size_t n, unsigned long long *out, hipStream_t s)
-{
-    if (n == 0)
-        return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(adcdac_loss_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n, out);
+    // a handful of small workgroups: the call runs beside a fused launch that leaves FRAME_RESERVE_BLOCKS workgroup slots free
+    const unsigned blocks = (unsigned)std::min<size_t>(FRAME_RESERVE_BLOCKS, (n_frames + 255) / 256);
+    hipLaunchKernelGGL(adcdac_verdict_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, payload_ok, check,
+                       n_loss, acc, host_out);
     return hipGetLastError();
 }
 

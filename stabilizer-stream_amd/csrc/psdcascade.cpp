@@ -60,6 +60,11 @@ struct DeviceSpan {
     const float *d_x = nullptr;
     uint64_t first = 0; // absolute index of d_x[0] in the stage-0 stream
     size_t len = 0;
+    // ... or trace fch of a run of AdcDac frames in device memory (d_x == nullptr): the samples are read in place as wire
+    // words (psdc_process_adcdac_frames_device), sample first + i of the stream = sample i of the trace
+    FrameSpan fs{};
+    int fch = 0;
+    bool framed() const { return fs.frames != nullptr; }
 };
 
 struct Channel {
@@ -114,7 +119,10 @@ struct psdc_handle {
     std::vector<Channel> ch;
     float *d_spectra = nullptr; // [n_channels][MAX_STAGES][n] accumulators, one slab
     float *h_read = nullptr;    // pinned bounce buffer for read-outs (MAX_STAGES * n floats)
-    unsigned long long *d_scan = nullptr; // 4 words: verdict of the device-side frame header scan + Loss sums
+    unsigned long long *d_scan = nullptr; // 5 words: accumulators of the device-side frame header scan + Loss sums (kept zero)
+    unsigned long long *h_scan = nullptr; // pinned: its four result words
+    hipStream_t scan_stream = nullptr;    // the scan runs beside the compute stream's work (the host waits for it alone)
+    std::vector<FrameSpan> fs_pool;       // frame spans named by this round's jobs (FusedJob::fspan ... index this until a launch maps them)
     float *d_pool = nullptr;    // [n_channels][MAX_STAGES][2][pool_cap] small stream buffers (deep stages)
     size_t pool_cap = 0;        // floats per pooled buffer
     bool idle = true;           // nothing ingested since the pipeline was last drained
@@ -433,6 +441,57 @@ int add_stage(psdc_handle *h, Channel &c)
     return PSDC_OK;
 }
 
+// index of a frame span in the round's pool (jobs name it by that index until launch_* maps it into the launch's table)
+int pool_fspan(psdc_handle *h, const FrameSpan &fs)
+{
+    for (size_t i = 0; i < h->fs_pool.size(); ++i)
+        if (h->fs_pool[i].frames == fs.frames && h->fs_pool[i].bytes == fs.bytes && h->fs_pool[i].frame_size == fs.frame_size &&
+            h->fs_pool[i].batches == fs.batches)
+            return (int)i;
+    h->fs_pool.push_back(fs);
+    return (int)h->fs_pool.size() - 1;
+}
+
+// copy job: `count` samples of a zero-copy span from absolute stream index `from` to dst (decoded on the way when the
+// span is a run of frames)
+TailJob span_copy(psdc_handle *h, const DeviceSpan &sp, uint64_t from, float *dst, size_t count)
+{
+    TailJob t{};
+    t.dst = dst;
+    t.count = (int)count;
+    if (sp.framed()) {
+        t.src = nullptr;
+        t.fspan = pool_fspan(h, sp.fs);
+        t.fch = sp.fch;
+        t.s_off = (unsigned)(from - sp.first);
+    } else {
+        t.src = sp.d_x + (from - sp.first);
+    }
+    return t;
+}
+
+// pool index -> index in a launch's own table (at most MAX_FSPANS distinct spans per launch: the planner holds a channel
+// to MAX_COALESCE = MAX_FSPANS spans per round, and the four traces of a span share one entry)
+struct FspanMap {
+    FrameSpan *table;
+    int used = 0;
+    int pool_of[MAX_FSPANS];
+    explicit FspanMap(FrameSpan *t) : table(t) {}
+    int map(const psdc_handle *h, int pool_idx)
+    {
+        if (pool_idx < 0)
+            return -1;
+        for (int i = 0; i < used; ++i)
+            if (pool_of[i] == pool_idx)
+                return i;
+        if (used >= MAX_FSPANS)
+            return -2;
+        pool_of[used] = pool_idx;
+        table[used] = h->fs_pool[(size_t)pool_idx];
+        return used++;
+    }
+};
+
 // The epilogue of a round -- fold its partials (RedJob), carry its stream tails (TailJob) -- is
 // not launched when the round ends: the next round starts with a copy launch of its own (the
 // zero-copy seams), and one launch does both.  Nothing on the device reads what the epilogue
@@ -445,8 +504,14 @@ int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
     std::vector<TailJob> tails;
     tails.reserve(h->pend_tail.size() + extra.size());
     auto add_tail = [&](const TailJob &t) {
-        for (int o = 0; o < t.count; o += kPiece)
-            tails.push_back({t.src + o, t.dst + o, std::min(kPiece, t.count - o)});
+        for (int o = 0; o < t.count; o += kPiece) {
+            TailJob q = t;
+            q.src = t.src ? t.src + o : nullptr;
+            q.dst = t.dst + o;
+            q.count = std::min(kPiece, t.count - o);
+            q.s_off = t.s_off + (unsigned)o;
+            tails.push_back(q);
+        }
     };
     for (const TailJob &t : h->pend_tail)
         add_tail(t);
@@ -459,8 +524,16 @@ int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
         for (; ri < nr && rb.njobs < MAX_JOBS; ++ri)
             rb.jobs[rb.njobs++] = h->pend_red[ri];
         TailBatch tb{};
-        for (; ti < nt && tb.njobs < MAX_JOBS; ++ti)
-            tb.jobs[tb.njobs++] = tails[ti];
+        FspanMap fm(tb.fspans);
+        for (; ti < nt && tb.njobs < MAX_JOBS; ++ti) {
+            TailJob q = tails[ti];
+            if (q.fspan >= 0 && (q.fspan = fm.map(h, q.fspan)) < 0) {
+                if (tb.njobs == 0)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
+                break; // this launch's table is full: the job opens the next one
+            }
+            tb.jobs[tb.njobs++] = q;
+        }
         HIPCHK(h, launch_post(rb, tb, h->stream));
     }
     h->pend_red.clear();
@@ -554,6 +627,7 @@ int ensure_partial(psdc_handle *h, size_t floats)
 }
 
 constexpr int MAX_COALESCE = 16; // zero-copy spans of one channel in one round
+static_assert(MAX_COALESCE <= MAX_FSPANS, "a launch's frame-span table holds every span of a round");
 
 struct Span { // one contiguous source of a (channel, stage) batch
     const float *src;
@@ -562,6 +636,8 @@ struct Span { // one contiguous source of a (channel, stage) batch
     uint64_t m_a, m_b;     // decimator outputs [m_a, m_b)
     bool fixed = false;    // src is not the start of the stage's stream buffer (caller memory or a
                            // seam region inside the buffer): leave it alone when buffers are re-based
+    int fpool = -1;        // >= 0: the source is trace fch of frame span fs_pool[fpool] read in place (src == nullptr)
+    int fch = 0;
 };
 
 struct Work {
@@ -655,19 +731,20 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             if (rc)
                 return rc;
             float *buf = s0.buf.p[s0.buf.cur];
-            seams.push_back({c.spans[0].d_x, buf + (c.spans[0].first - s0.buf.base), (int)cp0});
+            seams.push_back(span_copy(h, c.spans[0], c.spans[0].first, buf + (c.spans[0].first - s0.buf.base), (size_t)cp0));
             s0.buf.end = c.spans[0].first + cp0;
             for (size_t i = 1; i < ns; ++i) {
                 const Region &r = regions[ci][i];
                 const DeviceSpan &pv = c.spans[i - 1], &sp = c.spans[i];
                 const size_t back = (size_t)(sp.first - r.base);
-                seams.push_back({pv.d_x + (r.base - pv.first), buf + r.off, (int)back});
-                seams.push_back({sp.d_x, buf + r.off + back, (int)std::min<uint64_t>(seam, sp.len)});
+                seams.push_back(span_copy(h, pv, r.base, buf + r.off, back));
+                seams.push_back(span_copy(h, sp, sp.first, buf + r.off + back, (size_t)std::min<uint64_t>(seam, sp.len)));
             }
         }
         int rc = launch_deferred(h, seams); // with the last round's epilogue
         if (rc)
             return rc;
+        h->fs_pool.clear(); // every job that named a pooled span has been launched; this round's jobs pool theirs afresh
         HIPCHK(h, hipEventRecord(h->ev_post, h->stream)); // see order_upload
         h->post_marked = true;
     }
@@ -736,8 +813,14 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                             w.spans[w.nspans++] = {s.buf.p[s.buf.cur] + regions[ci][i].off, regions[ci][i].base,
                                                    j_lo, j_split, m_lo, m_split, true};
                     }
-                    if (j_hi > j_split || m_hi > m_split)
-                        w.spans[w.nspans++] = {sp.d_x, first, j_split, j_hi, m_split, m_hi, true};
+                    if (j_hi > j_split || m_hi > m_split) {
+                        Span ip{sp.d_x, first, j_split, j_hi, m_split, m_hi, true};
+                        if (sp.framed()) {
+                            ip.fpool = pool_fspan(h, sp.fs);
+                            ip.fch = sp.fch;
+                        }
+                        w.spans[w.nspans++] = ip;
+                    }
                     j_lo = j_hi;
                     m_lo = m_hi;
                 }
@@ -829,6 +912,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 return;
             DecJob dj{};
             dj.src = sp.src;
+            dj.fspan = sp.fpool;
+            dj.fch = sp.fch;
             dj.src_base = (long long)sp.src_base;
             dj.m0 = (long long)ma;
             dj.dst = nx->buf.p[nx->buf.cur ^ 1];
@@ -841,6 +926,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 return;
             SegJob sj{};
             sj.src = sp.src;
+            sj.fspan = sp.fpool;
+            sj.fch = sp.fch;
             sj.src_base = (long long)sp.src_base;
             sj.seg0 = (long long)sa;
             sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
@@ -859,16 +946,20 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             uint64_t fs = sp.seg_a;
             while ((g.hop / 8) * (fs + 1) < g.drain)
                 fs += 2;
-            uint64_t np = (fast_ok && nx && fs + 2 <= sp.seg_b) ? (sp.seg_b - fs) / 2 : 0;
+            const bool framed = sp.fpool >= 0;
+            uint64_t np = (fast_ok && nx && fs + 2 <= sp.seg_b && (!framed || fused_frames_supported((int)h->n))) ? (sp.seg_b - fs) / 2 : 0;
             const uint64_t fofs = (uint64_t)g.hop * fs - sp.src_base; // samples of this span in front of the pairs
-            const float *fsrc = sp.src + fofs;
+            const float *fsrc = framed ? nullptr : sp.src + fofs;
             const uint64_t mf0 = (g.hop / 8) * (fs + 1), mf1 = mf0 + (h->n / 8) * np;
-            if (np && ((reinterpret_cast<uintptr_t>(fsrc) & 15u) != 0 || mf0 < sp.m_a || mf1 > sp.m_b ||
-                       (fofs < need_pre && sp.src_base != 0)))
+            const bool aligned = framed ? (fofs & 3u) == 0 : (reinterpret_cast<uintptr_t>(fsrc) & 15u) == 0;
+            if (np && (!aligned || mf0 < sp.m_a || mf1 > sp.m_b || (fofs < need_pre && sp.src_base != 0)))
                 np = 0;
             if (np) {
                 FusedJob fj{};
                 fj.src = fsrc;
+                fj.fspan = sp.fpool;
+                fj.fch = sp.fch;
+                fj.s_off = framed ? (unsigned)fofs : 0u;
                 fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
                 fj.npairs = (int)np;
                 fj.pre = (int)std::min<uint64_t>(fofs, HBF_HALO);
@@ -908,12 +999,36 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         }
     }
     const uint64_t teams = (uint64_t)std::max(1, fused_pairs_per_block((int)h->n, 1));
+    // Jobs that read frames in place go first in their launch, the four traces of one span side by side (same span, same
+    // offset: the same geometry, hence equal workgroup counts): the kernel deals such a group's workgroups over the XCDs so
+    // that the four readers of the same bytes share an L2 (FusedBatch::fg_*).
+    bool any_frames = false;
+    for (const PlanFused &pf : fjobs)
+        any_frames = any_frames || pf.j.fspan >= 0;
+    if (any_frames)
+        std::stable_sort(fjobs.begin(), fjobs.end(), [](const PlanFused &a, const PlanFused &b) {
+            const bool fa = a.j.fspan >= 0, fb = b.j.fspan >= 0;
+            if (fa != fb)
+                return fa;
+            if (!fa)
+                return false;
+            if (a.j.fspan != b.j.fspan)
+                return a.j.fspan < b.j.fspan;
+            if (a.j.s_off != b.j.s_off)
+                return a.j.s_off < b.j.s_off;
+            return a.j.fch < b.j.fch;
+        });
     for (size_t b0 = 0; b0 < fjobs.size(); b0 += MAX_JOBS) {
         const size_t b1 = std::min(fjobs.size(), b0 + (size_t)MAX_JOBS);
         // One run length R for the whole launch: the smallest R for which the jobs' workgroups
         // (ceil(pairs / (R teams)) each) fit the resident capacity.  A launch that asks for more
         // workgroups than are resident at once runs the surplus as a second wave behind the first.
-        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n);
+        // (A launch that reads frames leaves a few workgroup slots free: the header scan of the NEXT call runs on a
+        // side stream while this launch is resident, and would otherwise wait for it to drain.)
+        bool batch_frames = false;
+        for (size_t i = b0; i < b1; ++i)
+            batch_frames = batch_frames || fjobs[i].j.fspan >= 0;
+        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n) - (batch_frames ? (uint64_t)FRAME_RESERVE_BLOCKS : 0u);
         uint64_t pairs = 0;
         for (size_t i = b0; i < b1; ++i)
             pairs += (uint64_t)fjobs[i].j.npairs;
@@ -942,26 +1057,32 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // slab: the partials of one work are contiguous (fused first, then generic)
     std::vector<RedJob> rjobs(works.size());
     {
-        size_t slab = 0, fi = 0, si = 0;
+        // (the jobs of a work need not be adjacent in fjobs: frame jobs were moved to the front)
+        std::vector<size_t> nblk(works.size(), 0), base(works.size(), 0);
+        for (const PlanFused &pf : fjobs)
+            nblk[pf.work] += (size_t)pf.j.nblocks;
+        for (const PlanSeg &ps : sjobs)
+            nblk[ps.work] += (size_t)ps.j.nblocks;
+        size_t slab = 0;
         for (size_t wi = 0; wi < works.size(); ++wi) {
             RedJob &rj = rjobs[wi];
+            base[wi] = slab;
             rj.partial = h->d_partial + slab;
             rj.spectrum = h->ch[works[wi].c].st[works[wi].k].spectrum;
             rj.g_total = (float)works[wi].ew.g_total;
-            rj.nparts = 0;
-            for (; fi < fjobs.size() && fjobs[fi].work == wi; ++fi) {
-                fjobs[fi].j.partial = h->d_partial + slab;
-                slab += (size_t)fjobs[fi].j.nblocks * h->n;
-                rj.nparts += fjobs[fi].j.nblocks;
-            }
-            for (; si < sjobs.size() && sjobs[si].work == wi; ++si) {
-                sjobs[si].j.partial = h->d_partial + slab;
-                slab += (size_t)sjobs[si].j.nblocks * h->n;
-                rj.nparts += sjobs[si].j.nblocks;
-            }
+            rj.nparts = (int)nblk[wi];
+            slab += nblk[wi] * h->n;
         }
         if (slab > h->partial_cap)
             return fail(h, PSDC_ERR_DEVICE, "internal: partial slab overflow");
+        for (PlanFused &pf : fjobs) {
+            pf.j.partial = h->d_partial + base[pf.work];
+            base[pf.work] += (size_t)pf.j.nblocks * h->n;
+        }
+        for (PlanSeg &ps : sjobs) {
+            ps.j.partial = h->d_partial + base[ps.work];
+            base[ps.work] += (size_t)ps.j.nblocks * h->n;
+        }
     }
 
     // ---- launches: fused, generic welch, reduce, generic decimator -------
@@ -995,12 +1116,33 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     for (size_t i = 0; i < fjobs.size();) {
         FusedBatch fb{};
         fb.detrend = h->detrend;
+        FspanMap fm(fb.fspans);
         for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
             FusedJob j = fjobs[i].j;
             j.block_begin = fb.nblocks;
             fb.nblocks += j.nblocks;
             fb.any_ewma |= j.ewma;
+            if (j.fspan >= 0) {
+                fb.any_frames = 1;
+                if ((j.fspan = fm.map(h, j.fspan)) < 0)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
+            }
             fb.jobs[fb.njobs++] = j;
+        }
+        for (int a = 0; a + 3 < fb.njobs && fb.n_fgroups < MAX_FSPANS; ) { // the four traces of one span, side by side
+            const FusedJob *q = fb.jobs + a;
+            const bool group = q[0].fspan >= 0 && q[0].fch == 0 && q[1].fch == 1 && q[2].fch == 2 && q[3].fch == 3 &&
+                               q[1].fspan == q[0].fspan && q[2].fspan == q[0].fspan && q[3].fspan == q[0].fspan &&
+                               q[1].s_off == q[0].s_off && q[2].s_off == q[0].s_off && q[3].s_off == q[0].s_off &&
+                               q[1].nblocks == q[0].nblocks && q[2].nblocks == q[0].nblocks && q[3].nblocks == q[0].nblocks;
+            if (!group) {
+                ++a;
+                continue;
+            }
+            fb.fg_begin[fb.n_fgroups] = q[0].block_begin;
+            fb.fg_nb[fb.n_fgroups] = q[0].nblocks;
+            ++fb.n_fgroups;
+            a += 4;
         }
         ProfEvents pe{};
         const bool first = (i <= (size_t)MAX_JOBS);
@@ -1014,8 +1156,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         WelchBatch wb{};
         wb.hop = (int)g.hop;
         wb.detrend = h->detrend;
+        FspanMap fm(wb.fspans);
         for (; i < sjobs.size() && wb.njobs < MAX_JOBS; ++i) {
             SegJob j = sjobs[i].j;
+            if (j.fspan >= 0 && (j.fspan = fm.map(h, j.fspan)) < 0)
+                return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
             j.block_begin = wb.nblocks;
             wb.nblocks += j.nblocks;
             wb.jobs[wb.njobs++] = j;
@@ -1031,8 +1176,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     for (size_t i = 0; i < djobs.size();) {
         DecBatch db{};
         db.drain = (int)g.drain;
+        FspanMap fm(db.fspans);
         for (; i < djobs.size() && db.njobs < MAX_JOBS; ++i) {
             DecJob j = djobs[i];
+            if (j.fspan >= 0 && (j.fspan = fm.map(h, j.fspan)) < 0)
+                return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
             j.tile_begin = db.ntiles;
             db.ntiles += (j.nout + DEC_TILE - 1) / DEC_TILE;
             db.jobs[db.njobs++] = j;
@@ -1073,18 +1221,20 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             const bool span0 = (k == 0 && c.has_span());
             const DeviceSpan last = span0 ? c.spans.back() : DeviceSpan{};
             const uint64_t cnt = told > kf ? told - kf : 0;
-            const float *src = nullptr;
-            if (span0 && kf >= last.first)
-                src = last.d_x + (kf - last.first);
-            else if (span0)
+            if (span0 && kf < last.first)
                 return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
-            else if (cnt)
-                src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
             if (s.total - kf > s.buf.cap)
                 return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
             const int other = s.buf.cur ^ 1;
-            if (cnt)
-                tjobs.push_back({src, s.buf.p[other], (int)cnt});
+            if (cnt && span0) {
+                tjobs.push_back(span_copy(h, last, kf, s.buf.p[other], (size_t)cnt));
+            } else if (cnt) {
+                TailJob t{};
+                t.src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
+                t.dst = s.buf.p[other];
+                t.count = (int)cnt;
+                tjobs.push_back(t);
+            }
             s.buf.cur = other;
             s.buf.base = kf;
             s.buf.end = s.total;
@@ -1555,8 +1705,14 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_pool);
     if (h->h_read)
         (void)hipHostFree(h->h_read);
+    if (h->scan_stream) {
+        (void)hipStreamSynchronize(h->scan_stream);
+        (void)hipStreamDestroy(h->scan_stream);
+    }
     if (h->d_scan)
         (void)hipFree(h->d_scan);
+    if (h->h_scan)
+        (void)hipHostFree(h->h_scan);
     for (int i = 0; i < 2; ++i) {
         if (h->d_frames[i])
             (void)hipFree(h->d_frames[i]);
@@ -1980,32 +2136,34 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
         return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
     const size_t payload = frame_size - 8;
     const int batches = (int)(payload / 64);
-    // order behind anything pending on these channels
-    bool pend = false;
+    // host-fed samples staged on these channels come first in their streams
     for (int ci = 0; ci < 4; ++ci)
-        pend = pend || h->ch[ci].has_span() || h->ch[ci].submitted || h->ch[ci].fill;
-    if (pend) {
-        rc = flush_all(h);
-        if (rc)
-            return rc;
+        if (h->ch[ci].fill || h->ch[ci].submitted) {
+            rc = flush_all(h);
+            if (rc)
+                return rc;
+            break;
+        }
+    // Headers are checked on the device (the frames are there) and the Loss counters summed there too, over all frames at
+    // first -- the common case has no bad frame -- and again over the accepted ones if there was one.  The scan is ONE small
+    // launch on a stream of its own and the host waits for that launch alone: the compute stream keeps working on the rounds
+    // of earlier calls meanwhile (their fused launches leave FRAME_RESERVE_BLOCKS workgroup slots free for it), so the verdict
+    // -- which frames are ingested is known, and reported, when the call returns, as the reference's per-frame `?` does
+    // (src/source.rs:139) -- costs the device no idle time.  Four words come back through pinned memory: {~(first bad frame
+    // << 2 | error) or 0, batches received, sequence gaps, first seq | next seq << 32}.
+    if (!h->d_scan) {
+        HIPCHK(h, hipMalloc(&h->d_scan, 5 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->d_scan, 0, 5 * sizeof(unsigned long long)));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_scan), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi)); // (hi = the numerically lowest = greatest priority)
+        HIPCHK(h, hipStreamCreateWithPriority(&h->scan_stream, hipStreamNonBlocking, hi));
     }
-    rc = wait_uploads(h);
-    if (rc)
-        return rc;
-    // headers are checked on the device (the frames are there) and the Loss counters summed there too, over all
-    // frames at first -- the common case has no bad frame -- and again over the accepted ones if there was one;
-    // the four words come back through the pinned read-out buffer: {~(first bad frame << 2 | error) or 0, batches
-    // received, sequence gaps, first seq | next seq << 32}
-    if (!h->d_scan)
-        HIPCHK(h, hipMalloc(&h->d_scan, 4 * sizeof(unsigned long long)));
-    const unsigned long long *res = reinterpret_cast<const unsigned long long *>(h->h_read);
+    const unsigned long long *res = h->h_scan;
     auto scan = [&](size_t n_loss, bool check) -> int {
-        HIPCHK(h, hipMemsetAsync(h->d_scan, 0, 4 * sizeof(unsigned long long), h->stream));
-        if (check)
-            HIPCHK(h, launch_adcdac_scan(d_frames, frame_size, n_frames, batches, payload % 64 == 0, h->d_scan, h->stream));
-        HIPCHK(h, launch_adcdac_loss(d_frames, frame_size, n_loss, h->d_scan, h->stream));
-        HIPCHK(h, launch_copy_out(h->h_read, reinterpret_cast<const float *>(h->d_scan), 8, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, launch_adcdac_verdict(d_frames, frame_size, n_frames, batches, payload % 64 == 0, check ? 1 : 0, n_loss, h->d_scan,
+                                        h->h_scan, h->scan_stream));
+        HIPCHK(h, hipStreamSynchronize(h->scan_stream));
         return PSDC_OK;
     };
     rc = scan(n_frames, true);
@@ -2035,11 +2193,73 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
     }
     if (good && batches > 0) {
         h->idle = false;
-        // decoded into the stage-0 stream buffers in pieces of <= 2^24 samples per trace, each piece a round
-        const size_t piece_frames = std::max<size_t>(1, ((size_t)1 << 24) / ((size_t)batches * 8));
+        const size_t per_frame = (size_t)batches * 8; // samples per trace and frame
+        const bool in_place_ok = fused_frames_supported((int)h->n) && h->window_kind == PSDC_WINDOW_HANN;
+        // pieces of <= FSPAN_MAX_SAMPLES samples per trace (the kernels' cell arithmetic) / 2^24 on the decode path
+        const size_t piece_frames = std::max<size_t>(1, (in_place_ok ? (size_t)FSPAN_MAX_SAMPLES : ((size_t)1 << 24)) / per_frame);
         for (size_t f0 = 0; f0 < good; f0 += piece_frames) {
             const size_t cnt = std::min(piece_frames, good - f0);
-            const size_t per_ch = cnt * (size_t)batches * 8;
+            const size_t per_ch = cnt * per_frame;
+            const uint8_t *piece = d_frames + f0 * frame_size;
+            if (in_place_ok && per_ch >= (size_t)4 * (h->n + HBF_HALO)) {
+                // The four traces are read IN PLACE, as wire words, by the stage-0 loads of the fused kernel: a zero-copy span
+                // per trace, exactly like psdc_process_device's -- held back while the device is busy so that calls share rounds.
+                bool flush = false;
+                for (int ci = 0; ci < 4; ++ci) {
+                    Channel &c = h->ch[ci];
+                    flush = flush || c.submitted || c.fill > 0 || c.spans.size() >= h->coalesce;
+                }
+                bool any_span = false;
+                for (int ci = 0; ci < 4; ++ci)
+                    any_span = any_span || h->ch[ci].has_span();
+                if (flush || (any_span && device_idle(h))) {
+                    rc = flush_all(h);
+                    if (rc)
+                        return rc;
+                }
+                FrameSpan fs{};
+                fs.frames = piece;
+                fs.bytes = (unsigned long long)cnt * frame_size;
+                fs.frame_size = (unsigned)frame_size;
+                fs.batches = (unsigned)batches;
+                fs.magic = batches >= 2 ? (unsigned)((0x100000000ull + (unsigned)batches - 1) / (unsigned)batches) : 0u;
+                for (int ci = 0; ci < 4; ++ci) {
+                    Channel &c = h->ch[ci];
+                    if (c.st.empty()) {
+                        rc = add_stage(h, c);
+                        if (rc)
+                            return rc;
+                    }
+                    StageState &s0 = c.st[0];
+                    DeviceSpan sp;
+                    sp.first = s0.total;
+                    sp.len = per_ch;
+                    sp.fs = fs;
+                    sp.fch = ci;
+                    c.spans.push_back(sp);
+                    s0.total += per_ch;
+                    c.span_max = std::max(c.span_max, per_ch);
+                    if (c.spans.size() > 1)
+                        c.coalesced_seen = true;
+                }
+                // on an idle device nothing is held back; on a busy one the next call may share this one's round
+                if (h->ch[0].spans.size() >= h->coalesce || device_idle(h)) {
+                    rc = advance(h);
+                    if (rc)
+                        return rc;
+                }
+                continue;
+            }
+            // sizes / windows without an in-place kernel, and pieces too short to split: decoded into the stage-0 stream
+            // buffers by a kernel of their own, each piece a round
+            bool pend = false;
+            for (int ci = 0; ci < 4; ++ci)
+                pend = pend || h->ch[ci].has_span();
+            if (pend) {
+                rc = advance(h);
+                if (rc)
+                    return rc;
+            }
             float *dst[4];
             for (int ci = 0; ci < 4; ++ci) {
                 Channel &c = h->ch[ci];
@@ -2054,8 +2274,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                     return rc;
                 dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
             }
-            HIPCHK(h, launch_adcdac(d_frames + f0 * frame_size, frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3],
-                                    h->stream));
+            HIPCHK(h, launch_adcdac(piece, frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3], h->stream));
             for (int ci = 0; ci < 4; ++ci) {
                 h->ch[ci].st[0].total += per_ch;
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;

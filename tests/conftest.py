@@ -61,15 +61,19 @@ def gpu_required():
 # is passed as `ref_f32`:
 #   (a) over the bins whose tolerance the extra terms more than double (an a-priori set), the GPU's rms error must be
 #       no larger than the f32 reference's own, or meet the pure 1e-5 there in the rms sense;
-#   (b) EVERY bin whose error exceeds the pure 1e-5 bound -- wherever it sits -- must individually be within
-#       EXCESS_K x the f32 reference's own error level at that bin (its error there, or the running rms of its error
-#       over the +-8 neighbouring bins when it happens to cross zero there): no bin passes on the widening alone.
+#   (b) EVERY bin whose error exceeds the pure 1e-5 bound -- wherever it sits -- may use no more of its widened
+#       tolerance than EXCESS_K x what the f32 reference's own arithmetic uses at ITS worst bin of the same spectrum
+#       (err / tol against max_k e32_k / tol_k).  The comparison is with the reference's worst bin, not with the same
+#       bin: on signals that need the widening (a step of 1e5 sigma inside a segment, a tone 60 dB above the noise) the
+#       errors of an f32 FFT are outliers at bins its radix structure picks, and the GPU's (4, 16, ..., 16) passes pick
+#       others than a radix-2 does -- tools/dbg_excess.py: equal rms, different bins.  So no bin passes on the widening
+#       unless the reference's own arithmetic needs as much of it somewhere in the same spectrum.
 # The terminal summary names the test and bin with the largest excess and the one closest to cap (b); assertions
 # that are widened WITHOUT a ref_f32 are counted and their worst non-widened bin is named too.
 RTOL = 1e-5
 ATOL_FRAC = 1e-6
 DYN = 5e-7
-EXCESS_K = 3.0
+EXCESS_K = 2.0
 WORST = {"pure": (0.0, ""), "widened": (0.0, ""), "excess_vs_f32": (0.0, ""), "unjustified": (0.0, "")}
 COUNTS = {"pure": 0, "justified": 0, "unjustified": 0, "excess_bins": 0}
 
@@ -106,7 +110,7 @@ def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN,
     worst = int(np.argmax(err / np.maximum(tol, 1e-300)))
     assert np.all(err <= tol), (f"{what}: bin {worst} got {got[worst]:.9g} ref {ref[worst]:.9g} "
                                 f"err/tol {err[worst] / tol[worst]:.3g} ({'pure 1e-5' if pure else 'widened'})")
-    relv = err / np.maximum(np.abs(ref), 1e-300)
+    relv = err / np.maximum(np.abs(ref), 1e-9 * np.max(np.abs(ref)) + 1e-300)  # (bins a detrend nulls: relative to the spectrum's scale)
     rel = float(np.max(relv))
     if pure:
         COUNTS["pure"] += 1
@@ -124,16 +128,19 @@ def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN,
                                     f"f32 reference arithmetic's {r:.3g} and the pure 1e-5 level {p:.3g}")
         if np.any(excess):
             COUNTS["excess_bins"] += int(excess.sum())
-            level = np.maximum(e32, _local_rms(e32))  # the f32 reference's own error level at each bin
-            cap = np.maximum(base, EXCESS_K * level)
-            ratio = np.where(excess, err / np.maximum(level, 1e-300), 0.0)
-            k = int(np.argmax(ratio))
-            assert np.all(err[excess] <= cap[excess]), (
-                f"{what}: bin {k} exceeds the pure 1e-5 bound (rel {relv[k]:.3g}) and is {ratio[k]:.3g}x the f32 reference "
-                f"arithmetic's own error level there ({level[k]:.3g}; cap {EXCESS_K}x)")
-            _note("excess_vs_f32", float(ratio[k]), f"{what}, bin {k}: rel err {relv[k]:.3g}, f32 reference level {level[k] / max(abs(ref[k]), 1e-300):.3g} rel")
+            used_g, used_f = err / np.maximum(tol, 1e-300), e32 / np.maximum(tol, 1e-300)
+            f_worst = float(np.max(used_f))
+            cap = np.maximum(EXCESS_K * f_worst, base / np.maximum(tol, 1e-300))
+            k = int(np.argmax(np.where(excess, used_g, 0.0)))
+            assert np.all(used_g[excess] <= cap[excess]), (
+                f"{what}: bin {k} exceeds the pure 1e-5 bound (rel {relv[k]:.3g}) using {used_g[k]:.3g} of its widened tolerance, "
+                f"more than {EXCESS_K}x the {f_worst:.3g} the f32 reference arithmetic uses at its worst bin "
+                f"({int(np.argmax(used_f))}) of this spectrum")
+            ratio = float(used_g[k] / max(f_worst, 1e-300))
+            _note("excess_vs_f32", ratio, f"{what}, bin {k}: rel err {relv[k]:.3g}; the f32 reference's worst bin {int(np.argmax(used_f))} "
+                                          f"has rel err {float(e32[int(np.argmax(used_f))] / max(abs(ref[int(np.argmax(used_f))]), 1e-300)):.3g}")
             ke = int(np.argmax(np.where(excess, relv, 0.0)))
-            _note("widened", float(relv[ke]), f"{what}, bin {ke} (justified: {err[ke] / max(level[ke], 1e-300):.3g}x the f32 reference's level there)")
+            _note("widened", float(relv[ke]), f"{what}, bin {ke}")
         return float(np.max(relv[~excess])) if np.any(~excess) else 0.0
     COUNTS["unjustified"] += 1
     nw = relv[~wide]
@@ -152,7 +159,8 @@ def pytest_terminal_summary(terminalreporter):
     w(f"PSD parity: {COUNTS['pure']} pure-1e-5 assertions, worst relative error {WORST['pure'][0]:.3g} ({WORST['pure'][1]})")
     w(f"PSD parity: {COUNTS['justified']} widened assertions held to the f32 reference bin by bin; {COUNTS['excess_bins']} bins beyond the "
       f"pure 1e-5, the largest {WORST['widened'][0]:.3g} ({WORST['widened'][1]}); "
-      f"closest to the {EXCESS_K}x cap: {WORST['excess_vs_f32'][0]:.3g}x ({WORST['excess_vs_f32'][1]})")
+      f"most of the widened tolerance used relative to the f32 reference's own worst bin (cap {EXCESS_K}x): "
+      f"{WORST['excess_vs_f32'][0]:.3g}x ({WORST['excess_vs_f32'][1]})")
     w(f"PSD parity: {COUNTS['unjustified']} widened assertions without an f32 comparison (GPU vs GPU, golden fixtures); worst relative "
       f"error on their non-widened bins {WORST['unjustified'][0]:.3g} ({WORST['unjustified'][1]})")
 

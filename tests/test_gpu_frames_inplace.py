@@ -1,0 +1,138 @@
+"""AdcDac frames resident in HBM read IN PLACE by the stage-0 loads of the fused kernels (N >= 2048, Hann):
+psdc_process_adcdac_frames_device never writes the four f32 traces to memory -- a lane's four consecutive samples are
+one 8-byte load of wire words (src/de/data.rs:13), converted in registers (:28-35, :64, :75).  The traces the
+reference's decode produces (the oracle's restatement of src/de/frame.rs + src/de/data.rs), fed to oracle cascades,
+are the truth; counters, Loss (src/loss.rs) and de::Error behaviour as on the host-memory path."""
+import numpy as np
+import pytest
+
+from conftest import assert_psd_close
+from test_gpu_parity import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_frames(pkg, ora, nframes, batches, seed, seq0=0, scale=3000.0):
+    """(frame bytes as [nframes, frame_size] uint8, frame_size, the four traces as the reference decodes them)"""
+    rng = np.random.default_rng(seed)
+    raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8)) * scale), -32768, 32767).astype(np.int16)
+    data, fs = pkg.make_adcdac_frames(raw, batches, seq0=seq0)
+    buf = np.frombuffer(data, dtype=np.uint8).copy().reshape(nframes, fs)
+    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)
+    traces = [raw[c].astype(np.float32) * lsb for c in range(2)]
+    traces += [(raw[c].view(np.uint16) ^ np.uint16(0x8000)).view(np.int16).astype(np.float32) * lsb for c in (2, 3)]
+    for c in range(4):  # the oracle's own decode of a few frames, held against the vectorised one above
+        for f in (0, nframes // 2, nframes - 1):
+            st, _, nb, tr = ora.adcdac_decode(buf[f].tobytes())
+            assert st == 0 and nb == batches and np.array_equal(tr[c], traces[c][f * batches * 8:(f + 1) * batches * 8])
+    return buf, fs, traces
+
+
+@pytest.mark.parametrize("n,batches,detrend", [(2048, 22, "none"), (4096, 22, "none"), (4096, 7, "mean"), (4096, 1, "span"),
+                                               (8192, 31, "midpoint"), (16384, 22, "none"), (4096, 13, "none")])
+def test_frames_in_place(pkg, ora, gpu_required, n, batches, detrend):
+    """Uneven calls (long enough to be read in place, and short ones that are decoded), a read-out in between, the u32
+    sequence wrapping, a gap: every stage of the four cascades against the oracle on the decoded traces."""
+    import torch
+    per_frame = batches * 8
+    nframes = (160 * n) // per_frame + 37
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=n + batches, seq0=0xFFFFFFF0)
+    gap_at = nframes // 3
+    buf[gap_at:, 4:8] = (buf[gap_at:, 4:8].copy().view("<u4") + np.uint32(5 * batches)).view(np.uint8)  # 5 frames lost
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    cuts = [0, (40 * n) // per_frame + 3, (40 * n) // per_frame + 5, (97 * n) // per_frame, nframes]  # one 2-frame call
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert g.process_adcdac_frames_device(d.data_ptr() + a * fs, fs, b - a) == b - a
+        if a == cuts[1]:
+            g.num_stages(0)  # a read-out in mid-stream
+    assert g.loss() == {"received": nframes * batches, "dropped": 5 * batches}
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, detrend=detrend, channel=c,
+                             what=f"in-place frames N={n} B={batches} {detrend} {pkg.ADCDAC_TRACES[c]}")
+    g.close()
+
+
+def test_frames_in_place_coalesced_and_mixed(pkg, ora, gpu_required):
+    """Calls that share rounds (held back as on a busy device: coalesce = -4), then the same channels fed host
+    samples and an f32 device span behind the frames: one stream per trace whatever the source."""
+    import torch
+    n, batches = 4096, 22
+    per_frame = batches * 8
+    nframes = (300 * n) // per_frame
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=5)
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4)
+    g.configure(coalesce=-4)
+    step = nframes // 6
+    for a in range(0, 6 * step, step):
+        assert g.process_adcdac_frames_device(d.data_ptr() + a * fs, fs, step) == step
+    used = 6 * step * per_frame
+    extra = [pkg.noise_host(50 * n + 24, seed=40 + c) for c in range(4)]
+    dx = [torch.from_numpy(e[20 * n:]).cuda() for e in extra]
+    for c in range(4):
+        g.process(c, extra[c][:20 * n])
+        g.process_device(c, dx[c].data_ptr(), extra[c].size - 20 * n)
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c][:used], extra[c]], n, channel=c, what=f"coalesced frames + f32, trace {c}")
+    g.close()
+
+
+def test_frames_in_place_errors(pkg, ora, gpu_required):
+    """A bad frame in the middle of a long buffer: the frames before it are ingested (in place), the error is the
+    reference's (src/de/frame.rs:27-30, src/de/data.rs:23-24), later calls continue the streams."""
+    import torch
+    n, batches = 4096, 22
+    per_frame = batches * 8
+    nframes = (60 * n) // per_frame
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=9)
+    for pos, (byte, val, code) in enumerate([(0, 0x00, pkg.ERR_FRAME_HEADER), (2, 9, pkg.ERR_FRAME_FORMAT),
+                                             (3, batches + 1, pkg.ERR_FRAME_SIZE)]):
+        bad = buf.copy()
+        at = nframes // 2 + pos
+        bad[at, byte] = val
+        db = torch.from_numpy(bad.reshape(-1)).cuda()
+        g = pkg.PsdCascadeBank(n, 4)
+        with pytest.raises(pkg.FrameError) as e:
+            g.process_adcdac_frames_device(db.data_ptr(), fs, nframes)
+        assert e.value.code == code
+        assert g.loss()["received"] == at * batches
+        # the caller skips the bad frame and goes on, as the reference's loop does (src/bin/psd.rs:184)
+        assert g.process_adcdac_frames_device(db.data_ptr() + (at + 1) * fs, fs, nframes - at - 1) == nframes - at - 1
+        for c in range(4):
+            x = np.concatenate([traces[c][:at * per_frame], traces[c][(at + 1) * per_frame:]])
+            check_against_oracle(pkg, ora, g, [x], n, channel=c, what=f"bad frame {code}, trace {c}")
+        g.close()
+
+
+@pytest.mark.timeout(600)
+def test_config3_frames_in_place_full_size(pkg, ora, gpu_required):
+    """BASELINE config 3 with the frames resident in HBM, at full size (2^24 samples per trace, four calls): pure 1e-5
+    against the f64 oracle on every stage with four averages, and bit-identical accumulators whatever the call split
+    that keeps the same rounds (two handles fed the same calls)."""
+    import torch
+    n, batches = 4096, 22
+    nframes = -(-(1 << 24) // (8 * batches))
+    per = nframes * 8 * batches
+    lsb = np.float32(4.096 * 2.5 / 32768.0)
+    words = np.stack([np.clip(np.round(pkg.noise_host(per, 0x7654321 + c).astype(np.float64) * 4096), -32768, 32767)
+                      .astype(np.int16) for c in range(4)])
+    wire = words.copy()
+    wire[2:] = (wire[2:].view(np.uint16) ^ np.uint16(0x8000)).view(np.int16)  # DAC words are offset-binary on the wire
+    data, fs = pkg.make_adcdac_frames(wire, batches, seq0=0xFFFFF000)
+    d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    g, g2 = pkg.PsdCascadeBank(n, 4), pkg.PsdCascadeBank(n, 4)
+    q = nframes // 4
+    for h in (g, g2):
+        for i in range(4):
+            a, b = i * q, (nframes if i == 3 else (i + 1) * q)
+            assert h.process_adcdac_frames_device(d.data_ptr() + a * fs, fs, b - a) == b - a
+        h.sync()
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    for c in range(4):
+        xc = words[c].astype(np.float32) * lsb
+        w = check_against_oracle(pkg, ora, g, [xc], n, channel=c, what=f"config 3 in place {pkg.ADCDAC_TRACES[c]}", pure_min_count=4)
+        print(f"config 3 (frames in HBM, read in place) {pkg.ADCDAC_TRACES[c]}: worst relative error {w:.3g}")
+    g.close()
+    g2.close()
