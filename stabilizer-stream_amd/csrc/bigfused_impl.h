@@ -138,9 +138,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             if (fr) {
                 const unsigned si = s + 4u * (unsigned)k;
                 const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
-                typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                const u2v r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-                return make_float4(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), 0.0f, 0.0f);
+                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0); // (a GCC-style vector of two u32: index it)
+                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
             }
         }
         return c[k];

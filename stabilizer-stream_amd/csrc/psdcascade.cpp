@@ -1129,7 +1129,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             }
             fb.jobs[fb.njobs++] = j;
         }
-        for (int a = 0; a + 3 < fb.njobs && fb.n_fgroups < MAX_FSPANS; ) { // the four traces of one span, side by side
+        static const bool no_groups = getenv("PSDC_DBG_NOGROUPS") != nullptr; // (debugging aid)
+        for (int a = 0; !no_groups && a + 3 < fb.njobs && fb.n_fgroups < MAX_FSPANS; ) { // the four traces of one span, side by side
             const FusedJob *q = fb.jobs + a;
             const bool group = q[0].fspan >= 0 && q[0].fch == 0 && q[1].fch == 1 && q[2].fch == 2 && q[3].fch == 3 &&
                                q[1].fspan == q[0].fspan && q[2].fspan == q[0].fspan && q[3].fspan == q[0].fspan &&
@@ -2238,6 +2239,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                     sp.fch = ci;
                     c.spans.push_back(sp);
                     s0.total += per_ch;
+                    h->idle = false; // (a flush above may have drained the pipeline and marked it idle)
                     c.span_max = std::max(c.span_max, per_ch);
                     if (c.spans.size() > 1)
                         c.coalesced_seen = true;
@@ -2275,6 +2277,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                 dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
             }
             HIPCHK(h, launch_adcdac(piece, frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3], h->stream));
+            h->idle = false;
             for (int ci = 0; ci < 4; ++ci) {
                 h->ch[ci].st[0].total += per_ch;
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
