@@ -240,7 +240,11 @@ def main():
     ap.add_argument("--clock-warm-ms", type=float, default=300.0,
                     help="untimed run of the same kernels on a scratch cascade before the warm-up steps, so that short "
                          "timed regions do not measure the GPU's clock ramp")
-    ap.add_argument("--n", type=int, default=1024, help="FFT size N")
+    ap.add_argument("--n", type=int, default=None, help="FFT size N (default 1024; 4096 with --workload frames)")
+    ap.add_argument("--workload", default="raw", choices=["raw", "frames"],
+                    help="raw: f32 streams resident in HBM (the headline).  frames: BASELINE configs[2] as the MAIN leg -- 4-trace AdcDac "
+                         "frames (22 batches) resident in HBM, psdc_process_adcdac_frames_device, 2^log2-batch samples per trace per call "
+                         "(default 24); for the profiling passes of tools/gpu.sh")
     ap.add_argument("--log2-batch", type=int, default=None,
                     help="samples per channel per pass = 2^this (default 26 at --gpus 1, 24 at --gpus > 1)")
     ap.add_argument("--channels-per-gpu", type=int, default=None, help="default 1 at --gpus 1, 8 at --gpus > 1 (config 4)")
@@ -273,6 +277,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number as {args.gpus} GPUs")
     multi = args.gpus > 1
+    frames = args.workload == "frames"
+    if frames and multi:
+        raise SystemExit("--workload frames is a one-GPU leg")
+    if args.n is None:
+        args.n = 4096 if frames else 1024
+    if frames:
+        args.channels_per_gpu = 4
+        if args.log2_batch is None:
+            args.log2_batch = 24
     if args.channels_per_gpu is None:
         args.channels_per_gpu = 8 if multi else 1
     if args.log2_batch is None:
@@ -317,18 +330,34 @@ def main():
         bank.set_avg(pkg.AvgOpts(lim, cnt))
     # synthetic raw-f32 streams, generated on the device: channel c of rank r uses seed 0x7654321 + global channel
     bufs = []
-    for c in range(C):
-        d = torch.empty(T, dtype=torch.float32, device="cuda")
-        pkg.fill_noise_device(d.data_ptr(), T, seed=0x7654321 + rank * C + c, device=local_rank)
-        bufs.append(d)
+    FR_BATCHES = 22
+    if frames:  # 4 traces of T samples as AdcDac frames of 22 batches (1416 B), resident in HBM
+        fr_n = T // (FR_BATCHES * 8)
+        T = fr_n * FR_BATCHES * 8
+        rng = np.random.default_rng(1)
+        raw = np.clip(np.round(rng.standard_normal((4, T), dtype=np.float32) * 4096), -32768, 32767).astype(np.int16)
+        fr_data, fr_size = pkg.make_adcdac_frames(raw, FR_BATCHES)
+        bufs.append(torch.from_numpy(np.frombuffer(fr_data, dtype=np.uint8).copy()).cuda())
+        del raw, fr_data
+    else:
+        for c in range(C):
+            d = torch.empty(T, dtype=torch.float32, device="cuda")
+            pkg.fill_noise_device(d.data_ptr(), T, seed=0x7654321 + rank * C + c, device=local_rank)
+            bufs.append(d)
     torch.cuda.synchronize()
 
     P = args.passes
 
+    def feed(b):
+        if frames:
+            b.process_adcdac_frames_device(bufs[0].data_ptr(), fr_size, fr_n)
+        else:
+            for c in range(C):
+                b.process_device(c, bufs[c].data_ptr(), T)
+
     def step():
         for _ in range(P):
-            for c in range(C):
-                bank.process_device(c, bufs[c].data_ptr(), T)
+            feed(bank)
 
     def barrier():
         if dist is not None:
@@ -348,8 +377,7 @@ def main():
         tw = time.perf_counter()
         while (time.perf_counter() - tw) * 1e3 < args.clock_warm_ms:
             for _ in range(64):
-                for c in range(C):
-                    scratch.process_device(c, bufs[c].data_ptr(), T)
+                feed(scratch)
             scratch.sync()
         prof_scratch = scratch.profile_read()
         scratch.close()
@@ -413,23 +441,28 @@ def main():
         assert len(merged) == C * world
         reached = sum(1 for b in breaks if b.include)
         kern_s = prof["kernel_ms"] * 1e-3
-        ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
+        # algorithmic bytes per stage-0 sample: 4 for raw f32; frame bytes / samples for AdcDac frames
+        alg_bps = (fr_size / (FR_BATCHES * 8.0 * 4.0)) if frames else ALG_BYTES_PER_SAMPLE
+        ach = alg_bps * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
         kname = "fused_kernel" if n in (256, 512, 1024) else ("bigfused_kernel" if n <= 16384 and n >= 2048 else "welch_kernel")
         tr = measured_traffic(kname, n, C, T)
         out = {
-            "metric": "MS/s ingested (PsdCascade N=%d, raw f32)" % n,
+            "metric": "MS/s ingested (PsdCascade N=%d, %s)" % (n, "AdcDac frames, samples of the four traces" if frames else "raw f32"),
             "value": msps, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'BASELINE configs[3]' if multi else 'BASELINE configs[1]'}: {C * world}-channel raw f32 stream "
+            "config": {"workload": (f"BASELINE configs[2]: 4-trace AdcDac frames ({FR_BATCHES} batches, {fr_size} B) resident in HBM, read in place "
+                                    f"(psdc_process_adcdac_frames_device): " if frames else "") +
+                                   f"{'BASELINE configs[3]' if multi else 'BASELINE configs[1]'}: {C * world}-channel raw f32 stream "
                                    f"({C} per GPU), PsdCascade N={n}, Hann, detrend {args.detrend}, a step = {P} passes over "
                                    f"2^{args.log2_batch} samples/channel resident in HBM (the stream continues across passes), "
                                    f"{ns} stages instantiated ({reached} with count>=1)",
                        "fft_size": n, "channels": C * world, "channels_per_gpu": C,
                        "samples_per_pass_per_channel": T, "passes_per_step": P,
                        "samples_per_step_per_channel": T * P,
+                       "algorithmic_bytes_per_sample": alg_bps,
                        "stages": ns, "parallelism": f"channel-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
@@ -443,13 +476,13 @@ def main():
                                      if tr else None),  # = traffic_from_profiles (the contract's field name)
                          "traffic_over_algorithmic": (tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]) if tr else None,
                          "traffic_source": (tr["round"] + " PMC passes (one-span launches), profiles/") if tr else None,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / max(1, prof["launches"]),
+                         "algorithmic_bytes_per_launch": alg_bps * prof["stage0_samples"] / max(1, prof["launches"]),
                          "spans_per_launch": prof["stage0_samples"] / max(1, prof["launches"]) / (T * C),
                          "kernel": kname, "launches": prof["launches"],
                          "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
                          "avg_launch_ms_whole_process": prof_all["kernel_ms"] / max(1, prof_all["launches"]),
                          "launches_whole_process": prof_all["launches"],
-                         "algorithmic_bytes_per_sample": ALG_BYTES_PER_SAMPLE},
+                         "algorithmic_bytes_per_sample": alg_bps},
             "compute_roofline": {"bound": "fp32_valu", "achieved": flop * msps * 1e6 / 1e12 / world,
                                  "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": flop * msps * 1e6 / 1e12 / world / FP32_VALU_PEAK_TFLOPS,
@@ -457,7 +490,7 @@ def main():
         }
         bank.close()
         bank = None
-        if world == 1 and not args.no_other_configs and n == 1024 and C == 1:
+        if world == 1 and not args.no_other_configs and n == 1024 and C == 1 and not frames:
             # short legs of the other single-GPU configs, after (and outside) the headline's timed region
             del bufs
             torch.cuda.empty_cache()
@@ -469,7 +502,7 @@ def main():
             # the headline shape beyond the 256 MiB Infinity Cache (FETCH_SIZE counts fabric requests, MALL hits included)
             out["hbm_honest"] = side_leg_raw(pkg, torch, 1024, 28, local_rank, args.side_seconds)
         if not args.no_cpu_baseline:
-            if world == 1:
+            if world == 1 and not frames:
                 out["host_fed"] = host_fed_rate(pkg, n, local_rank)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, threads=max(1, min(C * world, cores)))

@@ -24,6 +24,24 @@ namespace psdk {
 #define PSDK_FFT_BARRIER() __syncthreads()
 #endif
 
+// -DPSDK_STAMPS (tools/stamps, ONE bigfused_<N>.hip at a time): wave 0 of workgroup 0 sums the s_memtime ticks between the
+// phase boundaries of pair_step into g_bstamps; never defined in the shipped build.
+#ifdef PSDK_STAMPS
+__device__ unsigned long long g_bstamps[16];
+#define PSDK_BSTAMP(k)                                                    \
+    do {                                                                  \
+        if (stamp_on) {                                                   \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+            bst[k] += t_ - tprev;                                         \
+            tprev = t_;                                                   \
+        }                                                                 \
+    } while (0)
+#else
+#define PSDK_BSTAMP(k) \
+    do {               \
+    } while (0)
+#endif
+
 template <int N>
 struct BigGeo : FusedDec<N> {
     using T = BlockFft<N>;
@@ -259,6 +277,23 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             eamp.init(job, job.step0 + 2 * p0);
     }
 
+    // The lane's own twiddle seeds (W_N^(4 tl); W_L1^s, W_L1^(4 s): fft_block.h) do not change from pair to pair: six registers
+    // held across the run instead of three L2 loads per pair -- pass A's two had nothing in front of them to hide their
+    // latency behind (stamps: 22 % of a pair at N = 4096).  The window (16 values a lane) stays a per-pair batch of loads.
+    // -DPSDK_HOIST_SEEDS=0: the round-2 form (all table loads inside the pair).
+#ifndef PSDK_HOIST_SEEDS
+#define PSDK_HOIST_SEEDS 1
+#endif
+    typename T::Seeds sd_run[VT];
+    typename T::SeedsA sda_run[VT];
+    if constexpr (PSDK_HOIST_SEEDS != 0) {
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            sd_run[v] = T::load_seeds(tp + THREADS * v, tw0g);
+            sda_run[v] = T::load_seeds_a(tp + THREADS * v, twag);
+        }
+    }
+
     // With several lanes per thread the scheduler must not interleave their sections (it would keep
     // every lane's butterflies and twiddles live at once): a scheduling barrier between lanes.
     auto lane_fence = [] {
@@ -266,6 +301,11 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             __builtin_amdgcn_sched_barrier(0);
     };
 
+#ifdef PSDK_STAMPS
+    const bool stamp_on = bid == 0 && run >= 4 && tp < 64;
+    unsigned long long bst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
     auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, unsigned snext,
                          bool more, float *o, int p) {
@@ -290,6 +330,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         } else {
             asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
         }
+        PSDK_BSTAMP(0); // between pairs
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
@@ -315,6 +356,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             split(h + 3 * N / 8, nl[v][1]);
         }
         __syncthreads();
+        PSDK_BSTAMP(1); // state + samples -> LDS (waits for the look-ahead loads) + barrier
 #pragma unroll
         for (int r = 0; r < 4 * VT; ++r) { // stage A: N/2 outputs, two per step
             const int u = tp + THREADS * r;
@@ -324,6 +366,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::AO + 11 + u] = y1;
         }
         __syncthreads();
+        PSDK_BSTAMP(2); // stage A + barrier
 #pragma unroll
         for (int r = 0; r < 2 * VT; ++r) { // stage B: N/4 outputs
             const int u = tp + THREADS * r;
@@ -333,6 +376,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::BO + 29 + u] = y1;
         }
         __syncthreads();
+        PSDK_BSTAMP(3); // stage B + barrier
         f2 yc[VT]; // stage C: N/8 outputs, two per lane; stored further down, see there
 #pragma unroll
         for (int r = 0; r < VT; ++r) {
@@ -391,6 +435,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             }
         }
         __syncthreads(); // the frame is reused by the FFT; s_red published
+        PSDK_BSTAMP(4); // stage C + state save + detrend prep + barrier
         if constexpr (DETREND == 1) {
             oa = s_red[0];
             ob = s_red[1];
@@ -433,7 +478,14 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             const int tl = tp + THREADS * v;
             const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
             const float4 wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
-            sd[v] = T::load_seeds(tl, tw0p);
+            if constexpr (PSDK_HOIST_SEEDS != 0) {
+                sd[v] = sd_run[v];
+                // (opaque per pair: the products formed from the seeds must not be hoisted out of the loop with them --
+                // left alone the compiler keeps every derived twiddle of the run live and spills 200 bytes a lane)
+                asm volatile("" : "+v"(sd[v].w0.re), "+v"(sd[v].w0.im));
+            } else {
+                sd[v] = T::load_seeds(tl, tw0p);
+            }
             window_pair<N, DETREND, EWMA, true>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
                                           wq2, wq3, dp);
             // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
@@ -443,10 +495,14 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             lane_fence();
         }
         __syncthreads();
+        PSDK_BSTAMP(5); // table loads + window + pass 0 + store + barrier
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadA(tp + THREADS * v, vv[v], frame);
-            T::passA(tp + THREADS * v, vv[v], T::load_seeds_a(tp + THREADS * v, twap));
+            typename T::SeedsA sa_ = PSDK_HOIST_SEEDS != 0 ? sda_run[v] : T::load_seeds_a(tp + THREADS * v, twap);
+            if constexpr (PSDK_HOIST_SEEDS != 0)
+                asm volatile("" : "+v"(sa_.a1.re), "+v"(sa_.a1.im), "+v"(sa_.a4.re), "+v"(sa_.a4.im));
+            T::passA(tp + THREADS * v, vv[v], sa_);
             T::storeA(tp + THREADS * v, vv[v], frame);
             lane_fence();
         }
@@ -475,6 +531,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             }
         }
         PSDK_FFT_BARRIER();
+        PSDK_BSTAMP(6); // pass A (seeds from L2) + output store + look-ahead issue + barrier
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadB(tp + THREADS * v, vv[v], frame);
@@ -483,6 +540,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             lane_fence();
         }
         PSDK_FFT_BARRIER();
+        PSDK_BSTAMP(7); // pass B + barrier
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             T::loadC(tp + THREADS * v, vv[v], frame);
@@ -502,6 +560,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             }
         }
         __syncthreads(); // next pair's decimator writes the frame
+        PSDK_BSTAMP(8); // pass C + |Z|^2 + barrier
     };
 
     {
@@ -520,6 +579,13 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         }
     }
 
+#ifdef PSDK_STAMPS
+    if (stamp_on && tp == 0) {
+        for (int k = 0; k < 12; ++k)
+            g_bstamps[k] = bst[k];
+        g_bstamps[12] = (unsigned long long)(p1 - p0);
+    }
+#endif
     // one team per workgroup: its accumulators are the partial
     float *out = job.partial + (size_t)wb * N;
 #pragma unroll
@@ -558,3 +624,10 @@ hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw
 }
 
 } // namespace psdk
+
+#ifdef PSDK_STAMPS
+extern "C" int psdc_debug_stamps_big(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(psdk::g_bstamps), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -11,8 +11,10 @@ namespace psdk {
 __device__ __forceinline__ unsigned frame_cell_offset(const FrameSpan &fs, unsigned cell)
 {
     const unsigned f = fs.batches == 1 ? cell : __umulhi(cell, fs.magic); // cell / batches
-    const unsigned b = cell - f * fs.batches;
-    return f * fs.frame_size + 8u + b * 64u;
+    // (24-bit multiplies -- full rate, where v_mul_lo_u32 is quarter rate: f < 2^24, batches < 2^8, frame_size < 2^24,
+    // products below 2^32)
+    const unsigned b = cell - __umul24(f, fs.batches);
+    return __umul24(f, fs.frame_size) + 8u + b * 64u;
 }
 
 __device__ __forceinline__ float adcdac_lsb() { return 4.096f * 2.5f / 32768.0f; } // src/de/data.rs:28-35 (one constant, asserted equal)

@@ -449,35 +449,56 @@ __global__ __launch_bounds__(256) void adcdac_verdict_kernel(const uint8_t *__re
                                                              int batches, int payload_ok, int check, size_t n_loss,
                                                              unsigned long long *acc, unsigned long long *host_out)
 {
-    auto seq_of = [&](size_t f) {
+    // the 8 header bytes of frame f as two words {magic | id << 16 | batches << 24, seq}: one 8-byte load when the frames are
+    // 8-byte aligned (frame_size = 8 + 64 B always is; the base is the caller's), bytes otherwise.  Every header is a cache
+    // line of its own, so the scan is latency-bound: four frames (eight loads) in flight per thread.
+    const bool aligned = ((reinterpret_cast<uintptr_t>(frames) | frame_size) & 7u) == 0;
+    auto header = [&](size_t f) -> uint2 {
         const uint8_t *p = frames + f * frame_size;
-        return (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+        if (aligned)
+            return *reinterpret_cast<const uint2 *>(p);
+        return make_uint2((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24),
+                          (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24));
     };
     unsigned long long rec = 0, drop = 0, bad = 0;
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (size_t)gridDim.x * 256) {
-        const uint8_t *p = frames + f * frame_size;
-        if (check) {
-            int code = 0;
-            if (p[0] != 0x7b || p[1] != 0x05)
-                code = 1;
-            else if (p[2] != 1)
-                code = 2;
-            else if (!payload_ok || (int)p[3] != batches)
-                code = 3;
-            if (code) {
-                const unsigned long long key = ~(((unsigned long long)f << 2) | (unsigned long long)code);
-                bad = key > bad ? key : bad;
-            }
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t f0 = (size_t)blockIdx.x * 256 + threadIdx.x; f0 < n_frames; f0 += 4 * stride) {
+        uint2 h[4], hp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t f = f0 + (size_t)u * stride;
+            const bool in = f < n_frames;
+            h[u] = in ? header(f) : make_uint2(0, 0);
+            hp[u] = (in && f > 0 && f < n_loss) ? header(f - 1) : make_uint2(0, 0);
         }
-        if (f < n_loss) {
-            const uint32_t b = p[3];
-            rec += b;
-            if (f > 0)
-                drop += (uint32_t)(seq_of(f) - (seq_of(f - 1) + (uint32_t)frames[(f - 1) * frame_size + 3]));
-            if (f == 0)
-                atomicOr(acc + 3, (unsigned long long)seq_of(0));
-            if (f == n_loss - 1)
-                atomicOr(acc + 3, (unsigned long long)(uint32_t)(seq_of(f) + b) << 32);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t f = f0 + (size_t)u * stride;
+            if (f >= n_frames)
+                continue;
+            const uint32_t w = h[u].x, b = w >> 24;
+            if (check) {
+                int code = 0;
+                if ((w & 0xffffu) != 0x057bu) // magic [0x7b, 0x05]
+                    code = 1;
+                else if (((w >> 16) & 0xffu) != 1u)
+                    code = 2;
+                else if (!payload_ok || (int)b != batches)
+                    code = 3;
+                if (code) {
+                    const unsigned long long key = ~(((unsigned long long)f << 2) | (unsigned long long)code);
+                    bad = key > bad ? key : bad;
+                }
+            }
+            if (f < n_loss) {
+                rec += b;
+                if (f > 0)
+                    drop += (uint32_t)(h[u].y - (hp[u].y + (hp[u].x >> 24)));
+                if (f == 0)
+                    atomicOr(acc + 3, (unsigned long long)h[u].y);
+                if (f == n_loss - 1)
+                    atomicOr(acc + 3, (unsigned long long)(uint32_t)(h[u].y + b) << 32);
+            }
         }
     }
     __shared__ unsigned long long s_rec[256], s_drop[256], s_bad[256];
@@ -520,7 +541,8 @@ hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_
     if (n_frames == 0)
         return hipSuccess;
     // a handful of small workgroups: the call runs beside a fused launch that leaves FRAME_RESERVE_BLOCKS workgroup slots free
-    const unsigned blocks = (unsigned)std::min<size_t>(FRAME_RESERVE_BLOCKS, (n_frames + 255) / 256);
+    // (a slot is four wavefronts of 128 registers, or more: four of these 256-thread, < 32-register workgroups fit one)
+    const unsigned blocks = (unsigned)std::min<size_t>(4 * FRAME_RESERVE_BLOCKS, (n_frames + 255) / 256);
     hipLaunchKernelGGL(adcdac_verdict_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, payload_ok, check,
                        n_loss, acc, host_out);
     return hipGetLastError();

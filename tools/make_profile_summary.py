@@ -83,7 +83,7 @@ if want("traffic"):
                 f.write(f"{r[0]},{r[1]},{r[2]},{r[3]}\n")
         b = bench_line(os.path.join(go, "pmc", f"{tag}_FETCH_SIZE_bench.log")) or {}
         cfg = b.get("config", {})
-        alg = 4 * cfg.get("samples_per_step_per_channel", 1 << 26) * cfg.get("channels", 1)
+        alg = int(cfg.get("algorithmic_bytes_per_sample", 4.0) * cfg.get("samples_per_step_per_channel", 1 << 26) * cfg.get("channels", 1))
         traffic = 2 * steady["FETCH_SIZE"] * 1024 + steady["WRITE_SIZE"] * 1024
         short = kern.split("(")[0].replace("void ", "").replace("psdk::", "")
         json.dump({
@@ -91,7 +91,7 @@ if want("traffic"):
             "workload": cfg.get("workload", "bench.py default") + "; one span per launch (--coalesce 1 --passes 1), "
                         "steady-state launches (all stages active)",
             "fft_size": cfg.get("fft_size"), "channels": cfg.get("channels"),
-            "samples_per_launch": alg // 4,
+            "samples_per_launch": cfg.get("samples_per_step_per_channel", 1 << 26) * cfg.get("channels", 1),
             "FETCH_SIZE_KiB": steady["FETCH_SIZE"], "WRITE_SIZE_KiB": steady["WRITE_SIZE"],
             "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "ratio": traffic / alg,
             "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts half of streaming reads; calibration "
