@@ -23,6 +23,12 @@ namespace psdk {
 #else
 #define PSDK_FFT_BARRIER() __syncthreads()
 #endif
+// more TIMING-ONLY ablations (wrong results): 512 = pass B without its exchange (its butterflies on the registers pass A left:
+// the cost of a three-pass (16, 16, 16) plan); 1024 = stage A without LDS on its input side (no polyphase sample arrays, no
+// reads: what a register / DPP stage A would leave, minus its moves)
+#ifndef PSDK_ABL
+#define PSDK_ABL 0
+#endif
 
 // -DPSDK_STAMPS (tools/stamps, ONE bigfused_<N>.hip at a time): wave 0 of workgroup 0 sums the s_memtime ticks between the
 // phase boundaries of pair_step into g_bstamps; never defined in the shipped build.
@@ -344,6 +350,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::XO + h] = x.y;
             sf[G::XO + h + 1] = x.w;
         };
+        if constexpr (!(PSDK_ABL & 1024)) {
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
@@ -356,11 +363,18 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             split(h + 3 * N / 8, nl[v][1]);
         }
         __syncthreads();
+        }
         PSDK_BSTAMP(1); // state + samples -> LDS (waits for the look-ahead loads) + barrier
 #pragma unroll
         for (int r = 0; r < 4 * VT; ++r) { // stage A: N/2 outputs, two per step
             const int u = tp + THREADS * r;
             float y0, y1;
+            if constexpr (PSDK_ABL & 1024) {
+                const float4 &a = r == 0 ? up[0][0] : r == 1 ? up[0][1] : r == 2 ? nl[0][0] : nl[0][1];
+                const float4 &b = r == 0 ? lo[0][1] : r == 1 ? up[0][0] : r == 2 ? up[0][1] : nl[0][0];
+                y0 = a.x + (a.y + b.w) * ta[0] + (b.y + a.w) * ta[1] + (b.z + a.z) * ta[2] + b.x;
+                y1 = a.z + (a.w + b.y) * ta[0] + (b.w + a.y) * ta[1] + (b.x + a.x) * ta[2] + b.z;
+            } else
             hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
             sf[G::AE + 11 + u] = y0;
             sf[G::AO + 11 + u] = y1;
@@ -534,15 +548,22 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         PSDK_BSTAMP(6); // pass A (seeds from L2) + output store + look-ahead issue + barrier
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
+            if constexpr (PSDK_ABL & 512) {
+                T::loadC(tp + THREADS * v, vv[v], frame); // (what pass A stored: same traffic as a real exchange)
+                T::passB(tp + THREADS * v, vv[v], s_twb);
+            } else {
             T::loadB(tp + THREADS * v, vv[v], frame);
             T::passB(tp + THREADS * v, vv[v], s_twb);
             T::storeB(tp + THREADS * v, vv[v], frame);
+            }
             lane_fence();
         }
+        if constexpr (!(PSDK_ABL & 512))
         PSDK_FFT_BARRIER();
         PSDK_BSTAMP(7); // pass B + barrier
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
+            if constexpr (!(PSDK_ABL & 512))
             T::loadC(tp + THREADS * v, vv[v], frame);
             T::passC(vv[v]);
 #pragma unroll

@@ -1029,27 +1029,50 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         for (size_t i = b0; i < b1; ++i)
             batch_frames = batch_frames || fjobs[i].j.fspan >= 0;
         const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n) - (batch_frames ? (uint64_t)FRAME_RESERVE_BLOCKS : 0u);
-        uint64_t pairs = 0;
-        for (size_t i = b0; i < b1; ++i)
-            pairs += (uint64_t)fjobs[i].j.npairs;
-        auto blocks_at = [&](uint64_t r) {
-            uint64_t nb = 0;
+        // Small jobs ride on top: a job whose one workgroup has at most a quarter of a full workgroup's work (the deep stages
+        // of every channel: a handful of pairs per round) does not count against the capacity.  Its workgroup goes FIRST in
+        // the grid, is resident for a few microseconds and leaves its slot to one of the surplus workgroups of the large
+        // jobs, so the launch asks for cap + (small jobs) workgroups and ends about one small job later than a launch of
+        // the large jobs alone -- where counting them against the capacity left their slots empty for nearly the whole launch
+        // (8 channels x 8 deep stages: 64 of 512 slots).
+        static const bool no_oversub = getenv("PSDC_NO_OVERSUB") != nullptr; // (A/B aid)
+        auto small_at = [&](uint64_t np, uint64_t r) { return !no_oversub && 4 * np <= r * teams; };
+        auto plan_r = [&](uint64_t r_small) { // the smallest R whose LARGE jobs fit the capacity, given which jobs count as small
+            uint64_t pairs = 0;
             for (size_t i = b0; i < b1; ++i)
-                nb += ((uint64_t)fjobs[i].j.npairs + r * teams - 1) / (r * teams);
-            return nb;
+                if (!small_at((uint64_t)fjobs[i].j.npairs, r_small))
+                    pairs += (uint64_t)fjobs[i].j.npairs;
+            auto blocks_at = [&](uint64_t r) {
+                uint64_t nb = 0;
+                for (size_t i = b0; i < b1; ++i)
+                    if (!small_at((uint64_t)fjobs[i].j.npairs, r_small))
+                        nb += ((uint64_t)fjobs[i].j.npairs + r * teams - 1) / (r * teams);
+                return nb;
+            };
+            uint64_t r = std::max<uint64_t>(1, (pairs + cap * teams - 1) / (cap * teams));
+            while (blocks_at(r) > cap)
+                ++r;
+            return r;
         };
-        uint64_t R = std::max<uint64_t>(1, (pairs + cap * teams - 1) / (cap * teams));
-        while (blocks_at(R) > cap)
-            ++R;
+        uint64_t R = plan_r(0); // every job counted
+        for (int it = 0; it < 3; ++it) {
+            const uint64_t rn = plan_r(R);
+            if (rn == R)
+                break;
+            R = rn;
+        }
         for (size_t i = b0; i < b1; ++i) {
             FusedJob &j = fjobs[i].j;
             const uint64_t np = (uint64_t)j.npairs;
-            const uint64_t nb = (np + R * teams - 1) / (R * teams);
+            const uint64_t nb = small_at(np, R) ? 1 : (np + R * teams - 1) / (R * teams);
             const uint64_t run = (np + nb * teams - 1) / (nb * teams); // evened out within the job (<= R)
             j.run = (int)run;
             j.nblocks = (int)((np + run * teams - 1) / (run * teams));
             blocks_total += (size_t)j.nblocks;
         }
+        // small jobs first in the grid (stable: the frame groups stay together behind them)
+        std::stable_partition(fjobs.begin() + (std::ptrdiff_t)b0, fjobs.begin() + (std::ptrdiff_t)b1,
+                              [&](const PlanFused &pf) { return small_at((uint64_t)pf.j.npairs, R); });
     }
     int rc = ensure_partial(h, blocks_total * h->n);
     if (rc)
