@@ -18,12 +18,14 @@
 // ordering is needed: there is no workgroup barrier in the loop.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include <hip/hip_ext.h>
 
 #include "fft_block.h"
 #include "fft_team.h"
+#include "frames.h"
 #include "fused_common.h"
 
 namespace psdk {
@@ -94,7 +96,10 @@ __device__ __forceinline__ float team_sum(float v)
 #ifndef PSDK_EWMA_WPS
 #define PSDK_EWMA_WPS FUSED_WAVES_PER_SIMD // the EWMA variants too (6 dwords spilled outside the loop; 2 waves/SIMD read 10 % lower)
 #endif
-template <int N, int DETREND, bool EWMA>
+// FRAMES: as in bigfused_impl.h -- jobs with fspan >= 0 read their stream in place from AdcDac frames (8-byte buffer loads of
+// four wire words, converted in the register group once the loads have landed); separate kernels, so the f32-only launches keep
+// their instruction stream and registers.
+template <int N, int DETREND, bool EWMA, bool FRAMES = false>
 __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVES_PER_SIMD) void fused_kernel(
     const FusedBatch batch, const float *__restrict__ win)
 {
@@ -130,11 +135,31 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     for (int i = tid; i < N / 4; i += FUSED_WAVES * 64)
         s_win[i] = *reinterpret_cast<const float4 *>(win + 4 * i); // (src/psd.rs:44-48 table)
 
+    int bid = blockIdx.x;
+    if constexpr (FRAMES) { // the four traces of a frame span on one XCD (see bigfused_impl.h)
+        for (int g = 0; g < batch.n_fgroups; ++g) {
+            const int b0 = batch.fg_begin[g], nb = batch.fg_nb[g];
+            if (bid >= b0 && bid < b0 + 4 * nb) {
+                const int p = bid - b0, full = (nb >> 3) * 32;
+                int c, w;
+                if (p < full) {
+                    c = (p >> 3) & 3;
+                    w = (p >> 5) * 8 + (p & 7);
+                } else {
+                    const int rem = nb & 7, q_ = p - full;
+                    c = q_ / rem;
+                    w = (nb & ~7) + q_ % rem;
+                }
+                bid = b0 + c * nb + w;
+                break;
+            }
+        }
+    }
     int ji = 0;
-    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
+    while (ji + 1 < batch.njobs && bid >= batch.jobs[ji + 1].block_begin)
         ++ji;
     const FusedJob &job = batch.jobs[ji];
-    const int wb = blockIdx.x - job.block_begin;
+    const int wb = bid - job.block_begin;
     const int npairs = job.npairs, run = job.run;
 
     cf *frame = s_frames + team * T::FRAME;
@@ -171,18 +196,57 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     const int nrun = min(run, npairs - p0);
     const bool act0 = nrun > 0;
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tl;
+    // ... or, in a FRAMES launch, trace job.fch of a frame span (sp: the sample index of the same piece within the span)
+    const bool fr = FRAMES && job.fspan >= 0;
+    const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
+    const unsigned ch_off = fr ? (unsigned)job.fch * 16u : 0u;
+    const unsigned dac_flip = (fr && job.fch >= 2) ? 0x80008000u : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(fsp.frames), 0, fr ? (int)min(fsp.bytes, 0x7FFFFFFFull) : 0, 0x00020000);
+    unsigned sp = job.s_off + (unsigned)p0 * N + 4u * tl;
+    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words in .x / .y
+    auto piece = [&](const float4 *c, unsigned s_, int k) -> float4 {
+        if constexpr (FRAMES) {
+            if (fr) {
+                const unsigned si = s_ + 4u * (unsigned)k;
+                const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0); // (a GCC-style vector of two u32: index it)
+                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+            }
+        }
+        return c[k];
+    };
+    auto volts = [&](float4 &g) { // raw wire words -> volts, in place (a no-op for f32 jobs)
+        if constexpr (FRAMES) {
+            if (fr) {
+                const unsigned a = __builtin_bit_cast(unsigned, g.x) ^ dac_flip, b = __builtin_bit_cast(unsigned, g.y) ^ dac_flip;
+                const float lsb = adcdac_lsb();
+                g.x = (float)(short)(unsigned short)(a & 0xffffu) * lsb;
+                g.y = (float)(short)(unsigned short)(a >> 16) * lsb;
+                g.z = (float)(short)(unsigned short)(b & 0xffffu) * lsb;
+                g.w = (float)(short)(unsigned short)(b >> 16) * lsb;
+            }
+        }
+    };
     // where the look-ahead loads go once there is nothing left to look ahead to: pieces that were
     // read before (every job holds at least one pair = 3N/2 samples)
     const float4 *safe = act0 ? cp : reinterpret_cast<const float4 *>(job.src) + tl;
+    unsigned safe_s = act0 ? sp : job.s_off + 4u * tl;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ga[2] = {z4, z4}, gb[2] = {z4, z4}, gc[2] = {z4, z4};
     if (act0) { // chunk p0 (all of it exists) and the lower half of chunk p0 + 1
-        ga[0] = cp[0];
-        ga[1] = cp[TEAM];
-        gb[0] = cp[2 * TEAM];
-        gb[1] = cp[3 * TEAM];
-        gc[0] = cp[N / 4];
-        gc[1] = cp[N / 4 + TEAM];
+        ga[0] = piece(cp, sp, 0);
+        ga[1] = piece(cp, sp, TEAM);
+        gb[0] = piece(cp, sp, 2 * TEAM);
+        gb[1] = piece(cp, sp, 3 * TEAM);
+        gc[0] = piece(cp, sp, N / 4);
+        gc[1] = piece(cp, sp, N / 4 + TEAM);
+        volts(ga[0]);
+        volts(ga[1]);
+        volts(gb[0]);
+        volts(gb[1]);
+        volts(gc[0]);
+        volts(gc[1]);
     }
 
     // ---- warm-up: filter state at the first new sample of the run ------------------------
@@ -195,8 +259,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             const int i0 = 2 * r - G::WX;
             float e = 0.0f, o = 0.0f;
             if (act0 && i0 >= lim) {
-                e = xn[i0];
-                o = xn[i0 + 1];
+                if (fr) {
+                    const unsigned long long si = (unsigned long long)((long long)job.s_off + (long long)p0 * N + N / 2 + i0);
+                    e = frame_sample(fsp, job.fch, si);
+                    o = frame_sample(fsp, job.fch, si + 1);
+                } else {
+                    e = xn[i0];
+                    o = xn[i0 + 1];
+                }
             }
             sf[G::WXE + r] = e;
             sf[G::WXO + r] = o;
@@ -253,7 +323,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
     // chunk p + 2 into `lo`, in flight during the FFT passes.  For pair p + 1 the roles are
     // (lo, up, nl) <- (nl, up, lo).
-    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, bool more,
+    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, unsigned snext, bool more,
                          float *o, int p) {
         // ---- decimator ------------------------------------------------------------------
         // (a handful of VALU instructions between LDS round trips: at raised priority the wavefront
@@ -417,12 +487,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
           // unconditionally (after the last pair: re-reads, unused) -- a load under a branch is
           // waited for at the branch's end, which would expose the HBM latency once per pair.
             const float4 *src = more ? cnext : safe;
+            const unsigned ssrc = more ? snext : safe_s;
             safe = src;
+            safe_s = ssrc;
             if constexpr (!(PSDK_ABL & 64)) {
-            up[0] = src[2 * TEAM];
-            up[1] = src[3 * TEAM];
-            lo[0] = src[N / 4];
-            lo[1] = src[N / 4 + TEAM];
+            up[0] = piece(src, ssrc, 2 * TEAM);
+            up[1] = piece(src, ssrc, 3 * TEAM);
+            lo[0] = piece(src, ssrc, N / 4);
+            lo[1] = piece(src, ssrc, N / 4 + TEAM);
             }
         }
         PSDK_STAMP(5);
@@ -465,6 +537,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+        if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
+            volts(up[0]);
+            volts(up[1]);
+            volts(lo[0]);
+            volts(lo[1]);
+        }
         wave_sync(); // next pair's decimator writes the frame
         PSDK_STAMP(8);
     };
@@ -472,12 +550,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
         for (int i = 0; i < nrun; i += 2) {
-            pair_step(ga, gb, gc, cp + N / 4, i + 1 < nrun, o, p0 + i);
+            pair_step(ga, gb, gc, cp + N / 4, sp + N, i + 1 < nrun, o, p0 + i);
             cp += N / 4;
+            sp += N;
             o += N / 8;
             if (i + 1 < nrun) {
-                pair_step(gc, gb, ga, cp + N / 4, i + 2 < nrun, o, p0 + i + 1);
+                pair_step(gc, gb, ga, cp + N / 4, sp + N, i + 2 < nrun, o, p0 + i + 1);
                 cp += N / 4;
+                sp += N;
                 o += N / 8;
             }
         }
@@ -513,7 +593,7 @@ bool fused_supported(int n)
     return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384;
 }
 
-bool fused_frames_supported(int n) { return n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+bool fused_frames_supported(int n) { return fused_supported(n); }
 
 int fused_pairs_per_block(int n, int run)
 {
@@ -528,6 +608,8 @@ int fused_pairs_per_block(int n, int run)
         return fused_supported(n) ? run : 0; // one team (the whole workgroup) per workgroup
     }
 }
+
+int fused_block_threads(int n) { return n >= 2048 ? n / 16 : FUSED_WAVES * 64; }
 
 // resident workgroups the launch is sized for (per CU: LDS and thread limits of each size)
 int fused_max_blocks(int n)
@@ -590,17 +672,34 @@ void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa)
     }
 }
 
+void fused_big3_table(int n, std::vector<cf> &tw3)
+{
+    tw3.clear();
+    if (n != 2048 && n != 4096)
+        return;
+    const int team = n / 16;
+    tw3.resize(2 * (size_t)team);
+    for (int tl = 0; tl < team; ++tl) {
+        const double a = -2.0 * M_PI * (double)tl / (double)n;
+        tw3[tl] = {(float)cos(a), (float)sin(a)};
+        tw3[team + tl] = {(float)cos(4.0 * a), (float)sin(4.0 * a)};
+    }
+}
+
 template <int N>
 static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
-    if (b.any_frames)
-        return hipErrorInvalidValue; // the team-level kernels read f32 streams only (fused_frames_supported)
+
     static_assert(FusedGeo<N>::LDS_BYTES * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES) <= 163840,
                   "the workgroups of a CU (two of eight waves by default) share its 160 KiB of LDS");
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
 #define PSDK_FUSED_CASE(D)                                                                \
     case D:                                                                               \
-        if (b.any_ewma)                                                                   \
+        if (b.any_frames && b.any_ewma)                                                   \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
+        else if (b.any_frames)                                                            \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win); \
+        else if (b.any_ewma)                                                              \
             hipExtLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
         else                                                                              \
             hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win); \
@@ -621,12 +720,22 @@ hipError_t launch_bigfused_2048(const FusedBatch &, const float *, const cf *, c
 hipError_t launch_bigfused_4096(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
 hipError_t launch_bigfused_8192(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
 hipError_t launch_bigfused_16384(const FusedBatch &, const float *, const cf *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
+hipError_t launch_bigfused3_2048(const FusedBatch &, const float *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
+hipError_t launch_bigfused3_4096(const FusedBatch &, const float *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
 
-hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, hipStream_t s,
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, const cf *tw3g, hipStream_t s,
                         hipEvent_t ea, hipEvent_t eb)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
+    // N = 2048 / 4096: the three-pass kernels (bigfused3_impl.h).  PSDC_FFT3=0 selects the four-pass kernels (A/B aid).
+    static const bool fft3 = !(getenv("PSDC_FFT3") && getenv("PSDC_FFT3")[0] == '0');
+    if (fft3 && tw3g) {
+        if (n == 2048)
+            return launch_bigfused3_2048(b, win, tw3g, s, ea, eb);
+        if (n == 4096)
+            return launch_bigfused3_4096(b, win, tw3g, s, ea, eb);
+    }
     switch (n) {
     case 256:
         return launch_fused_n<256>(b, win, s, ea, eb);

@@ -174,11 +174,14 @@ bool fused_supported(int n);                 // N = 256 ... 16384
 bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
 int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
+int fused_block_threads(int n);              // threads of one such workgroup
 // twiddle tables in global memory for the workgroup-level kernels (N >= 2048); empty otherwise
 void fused_big_tables(int n, std::vector<cf> &tw0, std::vector<cf> &twa);
+// twiddle seeds of the three-pass kernels (N = 2048, 4096: fft_block3.h) [2][N/16]: W_N^tl, W_N^(4 tl); empty otherwise
+void fused_big3_table(int n, std::vector<cf> &tw3);
 // ev_a / ev_b (both or neither): events that receive the kernel's own start and stop times
 // (hipExtLaunchKernelGGL), for PSDC_OPT_PROFILE
-hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag,
+hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, const cf *tw3g,
                         hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);

@@ -114,6 +114,7 @@ struct psdc_handle {
     float *d_win = nullptr;
     cf *d_tw = nullptr;
     cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels
+    cf *d_tw3g = nullptr;                    // twiddle seeds of the three-pass kernels (N = 2048, 4096)
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
@@ -1028,7 +1029,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         bool batch_frames = false;
         for (size_t i = b0; i < b1; ++i)
             batch_frames = batch_frames || fjobs[i].j.fspan >= 0;
-        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n) - (batch_frames ? (uint64_t)FRAME_RESERVE_BLOCKS : 0u);
+        // (FRAME_RESERVE_BLOCKS slots of at least 256 threads' worth of registers each)
+        const uint64_t reserve = (uint64_t)FRAME_RESERVE_BLOCKS * (uint64_t)std::max(1, 256 / std::max(1, fused_block_threads((int)h->n)));
+        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n) - (batch_frames ? reserve : 0u);
         // Small jobs ride on top: a job whose one workgroup has at most a quarter of a full workgroup's work (the deep stages
         // of every channel: a handful of pairs per round) does not count against the capacity.  Its workgroup goes FIRST in
         // the grid, is resident for a few microseconds and leaves its slot to one of the surplus workgroups of the large
@@ -1172,7 +1175,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         const bool first = (i <= (size_t)MAX_JOBS);
         if ((rc = prof_begin(pe, false)))
             return rc;
-        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->stream, pe.a, pe.b));
+        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b));
         if ((rc = prof_end(pe, first, false)))
             return rc;
     }
@@ -1624,6 +1627,13 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
                 return dev_fail(e, "twiddle tables");
         }
     }
+    {
+        std::vector<cf> t3;
+        fused_big3_table((int)n, t3);
+        if (!t3.empty() && ((e = hipMalloc(&h->d_tw3g, sizeof(cf) * t3.size())) != hipSuccess ||
+                            (e = hipMemcpy(h->d_tw3g, t3.data(), sizeof(cf) * t3.size(), hipMemcpyHostToDevice)) != hipSuccess))
+            return dev_fail(e, "twiddle seeds");
+    }
     if ((e = hipMemcpy(h->d_win, win.data(), sizeof(float) * n, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(win)");
     if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
@@ -1755,6 +1765,8 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_tw0g);
     if (h->d_twag)
         (void)hipFree(h->d_twag);
+    if (h->d_tw3g)
+        (void)hipFree(h->d_tw3g);
     if (h->ev_upload)
         (void)hipEventDestroy(h->ev_upload);
     if (h->ev_post)

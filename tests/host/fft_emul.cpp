@@ -6,6 +6,7 @@
 #include "fft_core.h"
 #include "fft_team.h"
 #include "fft_block.h"
+#include "fft_block3.h"
 #include <cmath>
 #include <algorithm>
 #include <complex>
@@ -339,6 +340,102 @@ static int check_block()
     return (err < 3e-6) ? 0 : 1;
 }
 
+// three-pass workgroup FFT (fft_block3.h): values against an f64 FFT, every bin exactly once, LDS bank conflicts
+template <int N>
+static int check_block3()
+{
+    using T = BlockFft3<N>;
+    constexpr int TEAM = T::TEAM;
+    std::vector<cf> z(N), frame(T::FRAME), tw0(T::TW0_SIZE), tw1(T::TW1_SIZE);
+    srand(17 + N);
+    for (int i = 0; i < N; ++i) {
+        z[i].re = (float)rand() / RAND_MAX - 0.5f;
+        z[i].im = (float)rand() / RAND_MAX - 0.5f;
+    }
+    for (int tl = 0; tl < TEAM; ++tl) {
+        const double a = -2.0 * M_PI * (double)tl / (double)N;
+        tw0[tl] = {(float)cos(a), (float)sin(a)};
+        tw0[TEAM + tl] = {(float)cos(4 * a), (float)sin(4 * a)};
+    }
+    for (int q = 1; q < T::R1; ++q)
+        for (int s = 0; s < 16; ++s) {
+            const double a = -2.0 * M_PI * (double)(s * q) / (double)T::L1;
+            tw1[(q - 1) * 16 + s] = {(float)cos(a), (float)sin(a)};
+        }
+    std::vector<std::vector<cf>> regs(TEAM, std::vector<cf>(16));
+    for (int t = 0; t < TEAM; ++t)
+        for (int m = 0; m < 16; ++m)
+            regs[t][m] = z[t + TEAM * m];
+    for (int t = 0; t < TEAM; ++t) T::pass0(regs[t].data(), T::load_seeds(t, tw0.data()));
+    for (int t = 0; t < TEAM; ++t) T::store0(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::load1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::pass1(t, regs[t].data(), tw1.data());
+    for (int t = 0; t < TEAM; ++t) T::store1(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::load2(t, regs[t].data(), frame.data());
+    for (int t = 0; t < TEAM; ++t) T::pass2(regs[t].data());
+    std::vector<std::complex<double>> x(N), y(N);
+    for (int i = 0; i < N; ++i) x[i] = {z[i].re, z[i].im};
+    {
+        int bits = 0;
+        while ((1 << bits) < N) ++bits;
+        for (int i = 0; i < N; ++i) {
+            int r = 0;
+            for (int b = 0; b < bits; ++b) if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+            y[r] = x[i];
+        }
+        for (int len = 2; len <= N; len <<= 1)
+            for (int b = 0; b < N; b += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    auto w = std::polar(1.0, -2.0 * M_PI * k / len);
+                    auto u = y[b + k], t = w * y[b + k + len / 2];
+                    y[b + k] = u + t;
+                    y[b + k + len / 2] = u - t;
+                }
+    }
+    std::vector<double> got(N, -1.0);
+    double err = 0, pmax = 0, cerr = 0;
+    for (int k = 0; k < N; ++k) pmax = std::max(pmax, std::norm(y[k]));
+    for (int t = 0; t < TEAM; ++t)
+        for (int q = 0; q < 16; ++q) {
+            const int k = T::freq_of(t, q);
+            if (k < 0 || k >= N || got[k] >= 0) {
+                printf("block3<%d>: bad/duplicate k=%d\n", N, k);
+                return 1;
+            }
+            got[k] = (double)regs[t][q].re * regs[t][q].re + (double)regs[t][q].im * regs[t][q].im;
+            cerr = std::max(cerr, std::abs(std::complex<double>(regs[t][q].re, regs[t][q].im) - y[k]) / std::sqrt(pmax));
+        }
+    for (int k = 0; k < N; ++k) err = std::max(err, fabs(got[k] - std::norm(y[k])) / pmax);
+    long rd = 0, rdi = 0, wr = 0, wri = 0;
+    auto rd_instr = [&](auto addr) {
+        for (int w0 = 0; w0 < TEAM; w0 += 32) {
+            std::vector<int> sl;
+            for (int l = w0; l < w0 + 32; ++l) sl.push_back(addr(l));
+            rd += group_cycles(sl, 32), ++rdi;
+        }
+    };
+    auto wr_instr = [&](auto addr) {
+        for (int w0 = 0; w0 < TEAM; w0 += 16) {
+            std::vector<int> sl;
+            for (int l = w0; l < w0 + 16; ++l) sl.push_back(addr(l));
+            wr += group_cycles(sl, 16), ++wri;
+        }
+    };
+    for (int q = 0; q < 16; ++q)
+        wr_instr([&](int tl) { return tl + (tl >> 4) + T::STEP1 * q; });
+    for (int i = 0; i < T::NB1; ++i)
+        for (int m = 0; m < T::R1; ++m) {
+            auto a = [&](int tl) { return T::base1(tl) + T::STEP1 * i + 17 * m; };
+            rd_instr(a);
+            wr_instr(a);
+        }
+    for (int m = 0; m < 16; ++m)
+        rd_instr([&](int tl) { return 17 * tl + m; });
+    printf("block3<%5d> (16,%2d,16): max|dP|/Pmax=%.3g max|dX|/sqrt(Pmax)=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
+           N, T::R1, err, cerr, rd, rdi, wr, wri);
+    return (err < 3e-6 && cerr < 3e-6) ? 0 : 1;
+}
+
 int main()
 {
     int bad = 0;
@@ -361,6 +458,8 @@ int main()
     bad |= check_block<4096>();
     bad |= check_block<8192>();
     bad |= check_block<16384>();
+    bad |= check_block3<2048>();
+    bad |= check_block3<4096>();
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }

@@ -1,4 +1,4 @@
-"""AdcDac frames resident in HBM read IN PLACE by the stage-0 loads of the fused kernels (N >= 2048, Hann):
+"""AdcDac frames resident in HBM read IN PLACE by the stage-0 loads of the fused kernels (N >= 256, Hann):
 psdc_process_adcdac_frames_device never writes the four f32 traces to memory -- a lane's four consecutive samples are
 one 8-byte load of wire words (src/de/data.rs:13), converted in registers (:28-35, :64, :75).  The traces the
 reference's decode produces (the oracle's restatement of src/de/frame.rs + src/de/data.rs), fed to oracle cascades,
@@ -29,7 +29,9 @@ def make_frames(pkg, ora, nframes, batches, seed, seq0=0, scale=3000.0):
 
 
 @pytest.mark.parametrize("n,batches,detrend", [(2048, 22, "none"), (4096, 22, "none"), (4096, 7, "mean"), (4096, 1, "span"),
-                                               (8192, 31, "midpoint"), (16384, 22, "none"), (4096, 13, "none")])
+                                               (8192, 31, "midpoint"), (16384, 22, "none"), (4096, 13, "none"),
+                                               (256, 22, "none"), (512, 22, "mean"), (512, 3, "midpoint"), (1024, 22, "none"),
+                                               (1024, 9, "span")])
 def test_frames_in_place(pkg, ora, gpu_required, n, batches, detrend):
     """Uneven calls (long enough to be read in place, and short ones that are decoded), a read-out in between, the u32
     sequence wrapping, a gap: every stage of the four cascades against the oracle on the decoded traces."""

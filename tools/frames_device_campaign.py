@@ -1,4 +1,4 @@
-"""Fuzz of psdc_process_adcdac_frames_device with the frames read in place (N >= 2048): random batches per frame
+"""Fuzz of psdc_process_adcdac_frames_device with the frames read in place (N >= 256): random batches per frame
 (1..31), call sizes from a couple of frames to thousands, mid-stream read-outs, coalescing depths, detrends; the four
 traces must track their oracle cascades and the Loss counters.  usage: python tools/frames_device_campaign.py [first] [count]"""
 import os, sys, time, traceback
@@ -17,7 +17,7 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    n = [2048, 4096, 4096, 8192, 16384][seed % 5]
+    n = [2048, 4096, 256, 8192, 16384, 512, 1024, 4096][seed % 8]
     batches = int(rng.integers(1, 32))
     per_frame = batches * 8
     nframes = int(rng.integers(30 * n, 260 * n)) // per_frame
