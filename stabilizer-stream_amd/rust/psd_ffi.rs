@@ -204,6 +204,81 @@ impl<const N: usize> Drop for PsdCascade<N> {
 }
 
 // ---------------------------------------------------------------------------------------------
+// PsdBank<N>: all traces of a stream in ONE handle -- not a reference type; the three-line change to the receiver loop of
+// src/bin/psd.rs:174-182 / src/bin/stream_test.rs:46-55 that gets the batched path the kernels are tuned for (one round of
+// launches for all traces instead of one handle, stream and launch sequence per trace):
+//
+//     let mut dec = PsdBank::<{ 1 << 9 }>::new(4);                    // was: Vec<(&str, PsdCascade<_>)>, one per trace
+//     for (i, (_name, trace)) in traces.iter().enumerate() { dec.process(i, trace); }   // was: dec[i].1.process(trace)
+//     let (p, b) = dec.psd(i, &merge_opts);                           // was: dec[i].1.psd(&merge_opts)
+// ---------------------------------------------------------------------------------------------
+
+extern "C" {
+    fn psdc_process_adcdac_frames(h: *mut PsdcHandle, frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
+}
+
+pub struct PsdBank<const N: usize> {
+    h: NonNull<PsdcHandle>,
+    n_traces: usize,
+}
+
+unsafe impl<const N: usize> Send for PsdBank<N> {}
+
+impl<const N: usize> PsdBank<N> {
+    pub fn new(n_traces: usize) -> Self {
+        const HANN: c_int = 1;
+        Self { h: nonnull_or_panic(unsafe { psdc_create(N as u32, HANN, n_traces as u32, PSDC_DEVICE_DEFAULT) }), n_traces }
+    }
+    fn check(&self, rc: c_int) {
+        if rc < 0 {
+            let msg = unsafe { CStr::from_ptr(psdc_last_error(self.h.as_ptr())) };
+            panic!("psdcascade: {}", msg.to_string_lossy());
+        }
+    }
+    pub fn set_avg(&mut self, avg: AvgOpts) {
+        self.check(unsafe { psdc_set_avg(self.h.as_ptr(), avg.limit, avg.count) });
+    }
+    pub fn set_detrend(&mut self, d: Detrend) {
+        self.check(unsafe { psdc_set_detrend(self.h.as_ptr(), d as c_int) });
+    }
+    /// `PsdCascade::process` of trace `i`
+    pub fn process(&mut self, i: usize, x: &[f32]) {
+        assert!(i < self.n_traces);
+        self.check(unsafe { psdc_process(self.h.as_ptr(), i as u32, x.as_ptr(), x.len()) });
+    }
+    /// whole frames as `Source::get` reads them for `Data::File` / `Data::Udp` (src/source.rs:135-142,158-165): header checks,
+    /// `Loss` counting and `AdcDac::traces()` of src/de happen behind the call, the four traces land in traces 0..3.
+    /// Err(code) carries the `de::Error` of the first bad frame; the frames before it were ingested.
+    pub fn process_adcdac_frames(&mut self, frames: &[u8], frame_size: usize) -> Result<usize, i32> {
+        let mut ok = 0usize;
+        let rc = unsafe { psdc_process_adcdac_frames(self.h.as_ptr(), frames.as_ptr(), frame_size, frames.len() / frame_size, &mut ok) };
+        if rc < 0 { Err(rc) } else { Ok(ok) }
+    }
+    /// `PsdCascade::psd` of trace `i`
+    pub fn psd(&self, i: usize, opts: &MergeOpts) -> (Vec<f32>, Vec<Break>) {
+        let h = self.h.as_ptr();
+        let ns = unsafe { psdc_num_stages(h, i as u32) };
+        self.check(ns);
+        let ns = ns as usize;
+        let mut p = vec![0f32; ns * (N / 2 + 1)];
+        let mut b = vec![PsdcBreak::default(); ns];
+        let (mut plen, mut nb) = (0usize, 0usize);
+        self.check(unsafe {
+            psdc_psd(h, i as u32, opts.keep_overlap as c_int, opts.min_count, opts.keep_transition_band as c_int,
+                     p.as_mut_ptr(), p.len(), &mut plen, b.as_mut_ptr(), b.len(), &mut nb)
+        });
+        p.truncate(plen);
+        (p, b[..nb].iter().map(to_break).collect())
+    }
+}
+
+impl<const N: usize> Drop for PsdBank<N> {
+    fn drop(&mut self) {
+        unsafe { psdc_destroy(self.h.as_ptr()) }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Psd<N>: one stage with the reference's `PsdStage` trait (src/psd.rs:122-288), e.g. for the crate's
 // own test (src/psd.rs:615-632).  `pub use psd_gpu::Psd;` next to `PsdCascade` in src/lib.rs.
 // ---------------------------------------------------------------------------------------------
