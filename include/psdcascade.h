@@ -110,15 +110,17 @@ typedef struct psdc_profile {
 /* ---- lifecycle ----------------------------------------------------------- */
 
 /* PsdCascade::<N>::default() (src/psd.rs:408-423) for `n_channels` traces on HIP
- * device `device`.  n: power of two, 16 <= n <= 16384 (the reference takes any
- * N >= 2 with (N - overlap) % 8 == 0, src/psd.rs:138,247; this build ships the
- * fixed power-of-two FFT sizes).  Returns NULL on failure; psdc_last_error(NULL)
+ * device `device`.  n: a power of two 16 ... 16384, or ANY size 16 < n <= 8192 (the reference takes any
+ * N >= 2 with (N - overlap) % 8 == 0, src/psd.rs:138,247 -- rustfft plans any length, :418; with the Hann
+ * window's overlap N/2 that is every multiple of 16).  Returns NULL on failure; psdc_last_error(NULL)
  * explains.
  * Which kernels run: the single-pass fused kernels (stream read once: detrend +
  * window + FFT + |X|^2 + /8 decimator in one launch) exist for the HANN window and
- * n = 256 ... 16384 -- what the reference's binaries and BASELINE configs use.  The
- * rectangular window and n < 256 take the generic two-pass kernels (welch +
- * hbf_dec8: same results, the stream is read twice, about a third of the rate). */
+ * n = 256 ... 16384 (powers of two) -- what the reference's binaries and BASELINE configs use.  The
+ * rectangular window, caller-built windows, n < 256 and sizes that are not powers of two take the generic
+ * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about a third of the rate;
+ * sizes that are not powers of two evaluate the DFT in chirp-z form on a power-of-two transform of at
+ * least twice the length: two such transforms per segment pair). */
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
 
 /* The same with a caller-supplied `Window<N>` -- the struct is public with public fields `win`, `power`,

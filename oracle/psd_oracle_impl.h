@@ -88,13 +88,29 @@ typedef struct {
 
 static int SFX(fft_init)(SFX(ora_fft) * f, int n)
 {
-    if (n < 1 || (n & (n - 1)))
+    if (n < 1)
         return -1;
     f->n = n;
     f->fast = 0;
     f->fast_stages = 0;
     f->ftw = NULL;
     f->fbuf = NULL;
+    f->rev = NULL;
+    if (n & (n - 1)) {
+        /* Not a power of two (rustfft plans any length, src/psd.rs:418): the DFT by its definition, O(n^2), with the n
+         * twiddles exp(-2 pi i k/n) tabulated from f64 -- test infrastructure, exactness before speed */
+        f->tw_re = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+        f->tw_im = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+        f->fbuf = (REAL *)malloc(sizeof(REAL) * 2 * (size_t)n);
+        if (!f->tw_re || !f->tw_im || !f->fbuf)
+            return -1;
+        for (int k = 0; k < n; ++k) {
+            double a = -2.0 * M_PI * (double)k / (double)n;
+            f->tw_re[k] = (REAL)cos(a);
+            f->tw_im[k] = (REAL)sin(a);
+        }
+        return 0;
+    }
     int h = n / 2 > 0 ? n / 2 : 1;
     f->tw_re = (REAL *)malloc(sizeof(REAL) * (size_t)h);
     f->tw_im = (REAL *)malloc(sizeof(REAL) * (size_t)h);
@@ -222,6 +238,25 @@ static void SFX(fft_fast_forward)(const SFX(ora_fft) * f, REAL *c /* interleaved
 static void SFX(fft_forward)(const SFX(ora_fft) * f, REAL *c)
 {
     const int n = f->n;
+    if (!f->rev) { /* the DFT by definition (sizes that are not powers of two) */
+        REAL *y = f->fbuf;
+        for (int k = 0; k < n; ++k) {
+            REAL sr = 0, si = 0;
+            int idx = 0; /* (j k) mod n, incrementally */
+            for (int j = 0; j < n; ++j) {
+                const REAL wr = f->tw_re[idx], wi = f->tw_im[idx];
+                sr += c[2 * j] * wr - c[2 * j + 1] * wi;
+                si += c[2 * j] * wi + c[2 * j + 1] * wr;
+                idx += k;
+                if (idx >= n)
+                    idx -= n;
+            }
+            y[2 * k] = sr;
+            y[2 * k + 1] = si;
+        }
+        memcpy(c, y, sizeof(REAL) * 2 * (size_t)n);
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         int r = f->rev[i];
         if (r > i) {
@@ -611,7 +646,12 @@ void SFX(ora_cascade_free)(SFX(ora_cascade) * c)
 }
 
 /* cpu_baseline only: switch this cascade's FFT to the vectorisable radix-4 plan (same DFT, other rounding) */
-int SFX(ora_cascade_set_fast_fft)(SFX(ora_cascade) * c) { return c->fft.fast ? 0 : SFX(fft_fast_plan)(&c->fft); }
+int SFX(ora_cascade_set_fast_fft)(SFX(ora_cascade) * c)
+{
+    if (!c->fft.rev)
+        return -1; /* powers of two only */
+    return c->fft.fast ? 0 : SFX(fft_fast_plan)(&c->fft);
+}
 
 void SFX(ora_cascade_set_avg)(SFX(ora_cascade) * c, uint32_t limit, uint32_t count)
 { /* :431-436 */

@@ -169,7 +169,11 @@ constexpr int WELCH_MAX_BLOCKS = 1024; // persistent workgroups per launch (4 pe
 constexpr int DEC_TILE = 256; // decimator outputs per workgroup
 
 bool welch_supported(int n);
-hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s);
+// sizes that are not powers of two (16 < n <= 8192): the transform length M (a power of two >= 2n - 1) of the chirp-z form
+// the generic kernel evaluates the n-point DFT in; 0 for powers of two.  tw is then W_M^j (M entries), chirp[j] =
+// exp(i pi j^2 / n) (n entries), bhat = FFT_M of the chirp wrapped around M (M entries).
+int bluestein_size(int n);
+hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, const cf *chirp, const cf *bhat, hipStream_t s);
 bool fused_supported(int n);                 // N = 256 ... 16384
 bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run

@@ -238,6 +238,213 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
 }
 
 // ---------------------------------------------------------------------------
+// Welch kernel for an FFT size that is not a power of two
+// ---------------------------------------------------------------------------
+// rustfft plans any length (src/psd.rs:418 `plan_fft_forward(N)`); the reference only asks for (N - overlap) % 8 == 0
+// (:246-247).  Sizes other than 2^k run the same generic two-pass path with the N-point DFT evaluated as a chirp-z
+// (Bluestein) convolution on the power-of-two passes above: with c[n] = exp(i pi n^2 / N),
+//     X[k] = conj(c[k]) sum_n (z[n] conj(c[n])) c[k - n]
+// i.e. one forward FFT of length M >= 2N - 1 of y = z conj(c) (zero padded), a pointwise product with B = FFT_M(c wrapped),
+// and one inverse FFT (a forward one on the conjugate).  Only |X[k]|^2 is consumed (src/psd.rs:228-233): the final chirp
+// and the conjugations of the inverse are unit phases and drop out; the 1/M of the inverse is applied to the partial.
+// Two real segments ride one complex transform exactly as in welch_kernel (the DFT is linear).
+template <int M>
+struct BlueCfg {
+    using Plan = FftPlan<M>;
+    static constexpr int E = Plan::E;
+    static constexpr int TEAM = Plan::TEAM;
+    static constexpr int BLOCK = TEAM > 256 ? TEAM : 256;
+    static constexpr int TEAMS = BLOCK / TEAM;
+    static constexpr int SPT = (2 * TEAMS * 4 > 32) ? 2 * TEAMS * 4 : 32;
+    static constexpr int WAVES = BLOCK / 64;
+};
+
+template <int M>
+__global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(const WelchBatch batch, int n, const float *__restrict__ win,
+                                                                          const cf *__restrict__ twm, const cf *__restrict__ chirp,
+                                                                          const cf *__restrict__ bhat)
+{
+    using Cfg = BlueCfg<M>;
+    using P0 = PassInfo<M, 0>;
+    constexpr int E = Cfg::E, TEAM = Cfg::TEAM, TEAMS = Cfg::TEAMS, SPT = Cfg::SPT;
+    __shared__ cf frames[TEAMS * M];
+    __shared__ float red[Cfg::WAVES * 2];
+
+    int ji = 0;
+    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
+        ++ji;
+    const SegJob &job = batch.jobs[ji];
+    const int wb = blockIdx.x - job.block_begin;
+    const int team = threadIdx.x / TEAM;
+    const int t = threadIdx.x % TEAM;
+    cf *frame = frames + team * M;
+    const int hop = batch.hop;
+    const int detrend = batch.detrend;
+    const float inv_n = 1.0f / (float)n;
+
+    float q[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s)
+        q[s] = 0.0f;
+
+    for (int lt = wb; lt < job.ntiles; lt += job.nblocks) {
+    const int seg_lo = lt * SPT;
+    const int seg_hi = min(job.nseg, seg_lo + SPT);
+    const int npairs = (seg_hi - seg_lo + 1) >> 1;
+    for (int p0 = 0; p0 < npairs; p0 += TEAMS) {
+        const int p = p0 + team;
+        const int la = seg_lo + 2 * p;
+        const bool act_a = la < seg_hi, act_b = la + 1 < seg_hi;
+        const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
+        auto xa = [&](int j) { return job.src[ofs_a + j]; };
+        auto xb = [&](int j) { return job.src[ofs_a + hop + j]; };
+
+        float ra[E], rb[E];
+#pragma unroll
+        for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+            for (int m = 0; m < P0::R; ++m) {
+                const int nidx = P0::elem(t, i, m);
+                ra[i * P0::R + m] = (act_a && nidx < n) ? xa(nidx) : 0.0f;
+                rb[i * P0::R + m] = (act_b && nidx < n) ? xb(nidx) : 0.0f;
+            }
+
+        // detrend parameters as in welch_kernel (src/psd.rs:75-113)
+        float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
+        slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+        if (detrend == 1) {
+            oa = act_a ? xa(n / 2) : 0.0f;
+            ob = act_b ? xb(n / 2) : 0.0f;
+        } else if (detrend == 2) {
+            if (act_a) {
+                oa = xa(0);
+                sa = span_slope(oa, xa(n - 1), n);
+            }
+            if (act_b) {
+                ob = xb(0);
+                sb = span_slope(ob, xb(n - 1), n);
+            }
+        } else if (detrend == 3) {
+            auto team_sum2 = [&](float &pa, float &pb) {
+                constexpr int W = TEAM < 64 ? TEAM : 64;
+#pragma unroll
+                for (int o = W / 2; o > 0; o >>= 1) {
+                    pa += __shfl_xor(pa, o);
+                    pb += __shfl_xor(pb, o);
+                }
+                if constexpr (TEAM > 64) {
+                    constexpr int WPT = TEAM / 64;
+                    const int w = threadIdx.x >> 6;
+                    if ((threadIdx.x & 63) == 0) {
+                        red[2 * w] = pa;
+                        red[2 * w + 1] = pb;
+                    }
+                    __syncthreads();
+                    pa = 0.0f;
+                    pb = 0.0f;
+                    for (int i = 0; i < WPT; ++i) {
+                        pa += red[2 * (team * WPT + i)];
+                        pb += red[2 * (team * WPT + i) + 1];
+                    }
+                    __syncthreads();
+                }
+            };
+            float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+            for (int s = 0; s < E; ++s) { // (slots past the segment hold zeros)
+                pa += ra[s];
+                pb += rb[s];
+            }
+            team_sum2(pa, pb);
+            oa = pa * inv_n;
+            ob = pb * inv_n;
+            pa = 0.0f;
+            pb = 0.0f;
+#pragma unroll
+            for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+                for (int m = 0; m < P0::R; ++m)
+                    if (P0::elem(t, i, m) < n) {
+                        pa += ra[i * P0::R + m] - oa;
+                        pb += rb[i * P0::R + m] - ob;
+                    }
+            team_sum2(pa, pb);
+            ma = pa * inv_n;
+            mb = pb * inv_n;
+        }
+        float ampa = 1.0f, ampb = 1.0f;
+        if (job.ewma) {
+            ampa = ewma_amp(job, job.step0 + la);
+            ampb = ewma_amp(job, job.step0 + la + 1);
+        }
+
+        cf v[E];
+#pragma unroll
+        for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+            for (int m = 0; m < P0::R; ++m) {
+                const int s = i * P0::R + m;
+                const int nidx = P0::elem(t, i, m);
+                cf z = {0.0f, 0.0f};
+                if (nidx < n) {
+                    const float w = win[nidx];
+                    float a = ra[s], b = rb[s];
+                    if (detrend != 0) {
+                        a = fmaf(-(float)nidx, sa.lo, fmaf(-(float)nidx, sa.hi, a - oa)) - ma;
+                        b = fmaf(-(float)nidx, sb.lo, fmaf(-(float)nidx, sb.hi, b - ob)) - mb;
+                    }
+                    a *= w;
+                    b *= w;
+                    if (job.ewma) {
+                        a *= ampa;
+                        b *= ampb;
+                    }
+                    const cf c = chirp[nidx]; // y = z conj(c)
+                    z = {a * c.re + b * c.im, b * c.re - a * c.im};
+                }
+                v[s] = z;
+            }
+
+        fft_passes<M, 0>(t, v, frame, twm); // Y = FFT_M(y): slot s holds bin freq_of_slot<M>(t, s)
+        __syncthreads();                    // everybody's last-pass reads of the frame are done
+#pragma unroll
+        for (int s = 0; s < E; ++s) { // conj(Y B), back in natural order for the second transform
+            const int j = freq_of_slot<M>(t, s);
+            const cf u = cmul(v[s], bhat[j]);
+            frame[lds_swz<M>(j)] = {u.re, -u.im};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < P0::NB; ++i)
+#pragma unroll
+            for (int m = 0; m < P0::R; ++m)
+                v[i * P0::R + m] = frame[lds_swz<M>(P0::elem(t, i, m))];
+        fft_passes<M, 0>(t, v, frame, twm); // M conj(convolution): slot s holds output index freq_of_slot<M>(t, s)
+#pragma unroll
+        for (int s = 0; s < E; ++s)
+            q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+    }
+    }
+
+    // combine the teams; outputs 0 ... n - 1 of the convolution are the bins, in natural order; 1/M^2 of the inverse
+    float *fq = reinterpret_cast<float *>(frames);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < E; ++s)
+        fq[team * M + freq_of_slot<M>(t, s)] = q[s];
+    __syncthreads();
+    float *out = job.partial + (size_t)wb * n;
+    const float scale = 1.0f / ((float)M * (float)M);
+    for (int k = threadIdx.x; k < n; k += Cfg::BLOCK) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < TEAMS; ++g)
+            acc += fq[g * M + k];
+        out[k] = acc * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // /8 half-band decimator
 // ---------------------------------------------------------------------------
 
@@ -353,7 +560,7 @@ __device__ __forceinline__ void reduce_body(const RedJob &job, int n, int xblk)
     const bool live = k <= n / 2;
     double acc = 0.0; // f64 partial sums: the fold adds no rounding of its own
     if (live) {
-        const int km = (n - k) & (n - 1);
+        const int km = k ? n - k : 0; // (n - k) mod n: n need not be a power of two
         for (int t = slice; t < job.nparts; t += RED_SLICES) {
             const float *p = job.partial + (size_t)t * n;
             acc += (double)p[k] + (double)p[km];
@@ -550,6 +757,24 @@ hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_
 
 int welch_segments_per_tile(int n)
 {
+    switch (bluestein_size(n)) { // not a power of two: the tile of the chirp-z kernel of its transform size
+#define PSDK_CASE(MM) \
+    case MM:          \
+        return BlueCfg<MM>::SPT;
+        PSDK_CASE(32)
+        PSDK_CASE(64)
+        PSDK_CASE(128)
+        PSDK_CASE(256)
+        PSDK_CASE(512)
+        PSDK_CASE(1024)
+        PSDK_CASE(2048)
+        PSDK_CASE(4096)
+        PSDK_CASE(8192)
+        PSDK_CASE(16384)
+#undef PSDK_CASE
+    default:
+        break;
+    }
     switch (n) {
 #define PSDK_CASE(NN) \
     case NN:          \
@@ -571,12 +796,43 @@ int welch_segments_per_tile(int n)
     }
 }
 
+// smallest power of two M >= 2n - 1 for the chirp-z form of an n-point DFT (0: n is a power of two or out of range)
+int bluestein_size(int n)
+{
+    if (n < 16 || n > 8192 || (n & (n - 1)) == 0)
+        return 0;
+    int m = 32;
+    while (m < 2 * n - 1)
+        m <<= 1;
+    return m;
+}
+
 bool welch_supported(int n) { return welch_segments_per_tile(n) != 0; }
 
-hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, hipStream_t s)
+hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, const cf *chirp, const cf *bhat, hipStream_t s)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
+    switch (bluestein_size(n)) { // tw: W_M^j, chirp: exp(i pi j^2 / n), bhat: FFT_M of the wrapped chirp
+#define PSDK_CASE(MM)                                                                                          \
+    case MM:                                                                                                   \
+        hipLaunchKernelGGL(welch_bluestein_kernel<MM>, dim3(b.nblocks), dim3(BlueCfg<MM>::BLOCK), 0, s, b, n, win, tw, \
+                           chirp, bhat);                                                                       \
+        return hipGetLastError();
+        PSDK_CASE(32)
+        PSDK_CASE(64)
+        PSDK_CASE(128)
+        PSDK_CASE(256)
+        PSDK_CASE(512)
+        PSDK_CASE(1024)
+        PSDK_CASE(2048)
+        PSDK_CASE(4096)
+        PSDK_CASE(8192)
+        PSDK_CASE(16384)
+#undef PSDK_CASE
+    default:
+        break;
+    }
     switch (n) {
 #define PSDK_CASE(NN)                                                                            \
     case NN:                                                                                     \

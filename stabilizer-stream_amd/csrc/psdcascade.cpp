@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <complex>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,7 @@ struct psdc_handle {
     cf *d_tw = nullptr;
     cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels
     cf *d_tw3g = nullptr;                    // twiddle seeds of the three-pass kernels (N = 2048, 4096)
+    cf *d_chirp = nullptr, *d_bhat = nullptr; // chirp-z tables of a size that is not a power of two (launch_welch)
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
@@ -382,7 +384,9 @@ int resolve_device(int device)
     return (end && *end == 0 && v >= 0 && v < 1024) ? (int)v : -2; // -2: rejected as out of range below
 }
 
-bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1)) == 0; }
+// powers of two 16 ... 16384 (every kernel), or any other size 16 < n <= 8192 (rustfft plans any length, src/psd.rs:418): those
+// run the generic kernels with the DFT in chirp-z form (kernels.hip welch_bluestein_kernel)
+bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && ((n & (n - 1)) == 0 || bluestein_size((int)n) != 0); }
 
 // PsdStage::gain (src/psd.rs:279-283): (N/2 * count) as f32, then two f32 multiplies.  The
 // reference forms the product in u32, which overflows (panic in debug builds, wrap-around in
@@ -1196,7 +1200,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         const bool first = (i <= (size_t)MAX_JOBS);
         if (!prof_fused && (rc = prof_begin(pe, true)))
             return rc;
-        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->stream));
+        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->d_chirp, h->d_bhat, h->stream));
         if (!prof_fused && (rc = prof_end(pe, first, true)))
             return rc;
     }
@@ -1523,7 +1527,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
 {
     device = resolve_device(device);
     if (!valid_n(n) || !welch_supported((int)n)) {
-        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 16384]");
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 16384] or any size in [16, 8192]");
         return nullptr;
     }
     if (window_kind != PSDC_WINDOW_CUSTOM && !window_consts(n, window_kind, &wc)) {
@@ -1575,10 +1579,49 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
     else
         window_weights(n, window_kind, win.data());
     h->win_host = win;
-    std::vector<cf> tw(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const double a = -2.0 * M_PI * (double)i / (double)n;
+    // twiddles of the generic kernels' transform: length n, or -- n not a power of two -- the chirp-z length M with its tables
+    const uint32_t m_fft = bluestein_size((int)n) ? (uint32_t)bluestein_size((int)n) : n;
+    std::vector<cf> tw(m_fft);
+    for (uint32_t i = 0; i < m_fft; ++i) {
+        const double a = -2.0 * M_PI * (double)i / (double)m_fft;
         tw[i] = {(float)cos(a), (float)sin(a)};
+    }
+    std::vector<cf> chirp, bhat;
+    if (m_fft != n) {
+        // c[j] = exp(i pi j^2 / n): j^2 mod 2n in integers keeps the phase exact; B = FFT_M(c wrapped) by an f64 radix-2 FFT
+        std::vector<std::complex<double>> c(n), b(m_fft, 0.0);
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint64_t r = ((uint64_t)j * j) % (2ull * n);
+            c[j] = std::polar(1.0, M_PI * (double)r / (double)n);
+        }
+        b[0] = c[0];
+        for (uint32_t j = 1; j < n; ++j)
+            b[j] = b[m_fft - j] = c[j];
+        int bits = 0;
+        while ((1u << bits) < m_fft)
+            ++bits;
+        std::vector<std::complex<double>> y(m_fft);
+        for (uint32_t i = 0; i < m_fft; ++i) {
+            uint32_t r = 0;
+            for (int k = 0; k < bits; ++k)
+                if (i & (1u << k))
+                    r |= 1u << (bits - 1 - k);
+            y[r] = b[i];
+        }
+        for (uint32_t len = 2; len <= m_fft; len <<= 1)
+            for (uint32_t b0 = 0; b0 < m_fft; b0 += len)
+                for (uint32_t k = 0; k < len / 2; ++k) {
+                    const std::complex<double> w = std::polar(1.0, -2.0 * M_PI * (double)k / (double)len);
+                    const std::complex<double> u = y[b0 + k], t = w * y[b0 + k + len / 2];
+                    y[b0 + k] = u + t;
+                    y[b0 + k + len / 2] = u - t;
+                }
+        chirp.resize(n);
+        bhat.resize(m_fft);
+        for (uint32_t j = 0; j < n; ++j)
+            chirp[j] = {(float)c[j].real(), (float)c[j].imag()};
+        for (uint32_t j = 0; j < m_fft; ++j)
+            bhat[j] = {(float)y[j].real(), (float)y[j].imag()};
     }
     auto dev_fail = [&](hipError_t err, const char *what) -> psdc_handle * {
         fail(nullptr, PSDC_ERR_DEVICE, std::string("psdc_create: ") + what + ": " + hipGetErrorString(err));
@@ -1595,8 +1638,13 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
         return dev_fail(e, "hipStreamCreate");
     if ((e = hipMalloc(&h->d_win, sizeof(float) * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(win)");
-    if ((e = hipMalloc(&h->d_tw, sizeof(cf) * n)) != hipSuccess)
+    if ((e = hipMalloc(&h->d_tw, sizeof(cf) * m_fft)) != hipSuccess)
         return dev_fail(e, "hipMalloc(tw)");
+    if (!chirp.empty() && ((e = hipMalloc(&h->d_chirp, sizeof(cf) * chirp.size())) != hipSuccess ||
+                           (e = hipMalloc(&h->d_bhat, sizeof(cf) * bhat.size())) != hipSuccess ||
+                           (e = hipMemcpy(h->d_chirp, chirp.data(), sizeof(cf) * chirp.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                           (e = hipMemcpy(h->d_bhat, bhat.data(), sizeof(cf) * bhat.size(), hipMemcpyHostToDevice)) != hipSuccess))
+        return dev_fail(e, "chirp-z tables");
     if ((e = hipMalloc(&h->d_spectra, sizeof(float) * (size_t)n_channels * MAX_STAGES * n)) != hipSuccess)
         return dev_fail(e, "hipMalloc(spectra)");
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_read), sizeof(float) * (size_t)MAX_STAGES * n,
@@ -1636,7 +1684,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
     }
     if ((e = hipMemcpy(h->d_win, win.data(), sizeof(float) * n, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(win)");
-    if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * n, hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(cf) * m_fft, hipMemcpyHostToDevice)) != hipSuccess)
         return dev_fail(e, "hipMemcpy(tw)");
     return h;
 }
@@ -1767,6 +1815,10 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_twag);
     if (h->d_tw3g)
         (void)hipFree(h->d_tw3g);
+    if (h->d_chirp)
+        (void)hipFree(h->d_chirp);
+    if (h->d_bhat)
+        (void)hipFree(h->d_bhat);
     if (h->ev_upload)
         (void)hipEventDestroy(h->ev_upload);
     if (h->ev_post)

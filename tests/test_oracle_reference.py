@@ -288,3 +288,18 @@ def test_stream_test_tail_on_the_oracle(pkg, ora):
         tau *= 2.0
         n_tau += 1
     assert n_tau == int(np.log2(eff // 2)) + 1
+
+
+@pytest.mark.parametrize("n", [48, 80, 1200])
+def test_dft_by_definition_for_sizes_that_are_not_powers_of_two(ora, n):
+    """rustfft plans any length (src/psd.rs:418); the oracle evaluates such a DFT by its definition."""
+    rng = np.random.default_rng(n)
+    c = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    r = np.fft.fft(c)
+    assert np.max(np.abs(ora.fft_forward(c, "f64") - r)) <= 1e-12 * np.max(np.abs(r))
+    assert np.max(np.abs(ora.fft_forward(c, "f32") - r)) <= 5e-6 * np.max(np.abs(r))
+    o = ora.PsdCascade(n, "f64")
+    x = np.ones(n, dtype=np.float32)  # Hann of a constant: bins 0, 1 only; PSD[0] = n^2/4 / gain
+    o.process(x)
+    sp = o.stage_spectrum(0)
+    assert abs(sp[0] - (n / 2.0) ** 2) < 1e-6 * sp[0] and abs(sp[1] - (n / 4.0) ** 2) < 1e-6 * sp[1] and np.all(sp[2:] < 1e-9 * sp[0])
