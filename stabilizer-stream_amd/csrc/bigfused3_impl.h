@@ -75,7 +75,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     __shared__ cf s_frame[T::FRAME];
     __shared__ cf s_tw1[T::TW1_SIZE];
     __shared__ float s_hist[G::HIST];
-    __shared__ float s_red[2 * G::WAVES + 4];
+    __shared__ __attribute__((aligned(8))) float s_red[2 * G::WAVES + 4];
 
     const int tp = threadIdx.x; // = the lane tl of the team
     for (int i = tp; i < T::TW1_SIZE; i += THREADS) { // [(q-1)][s]: W_L1^(s q)
@@ -356,12 +356,10 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             sb = span_slope(ob, s_red[3], N);
         }
         if constexpr (DETREND == 3) {
-            float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < G::WAVES; ++w) {
-                s1 += s_red[4 + 2 * w];
-                s2 += s_red[5 + 2 * w];
-            }
+            // the wavefronts' partial sums: lane l reads those of wavefront l mod WAVES (one 8-byte read) and the group of
+            // WAVES lanes adds them up with DPP -- a loop over s_red is 2 WAVES LDS reads a lane (32 at N = 16384)
+            const f2 tw_ = ld2(s_red + 4 + 2 * (tp & (G::WAVES - 1)));
+            const float s1 = group_sum<G::WAVES>(tw_.x), s2 = group_sum<G::WAVES>(tw_.y);
             ob = piv;
             ma = (s0c + s1) * (1.0f / (float)N);
             mb = (s1 + s2) * (1.0f / (float)N);

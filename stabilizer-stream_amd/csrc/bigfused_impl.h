@@ -48,8 +48,8 @@ __device__ unsigned long long g_bstamps[16];
     } while (0)
 #endif
 
-template <int N>
-struct BigGeo : FusedDec<N> {
+template <int N, bool NOX = false>
+struct BigGeo : FusedDec<N, NOX> {
     using T = BlockFft<N>;
     static constexpr int TEAM = T::TEAM;          // lanes of the team
 // N = 16384: one lane per thread (1024 threads, four wavefronts per SIMD) now that the tables are not held in
@@ -64,9 +64,12 @@ struct BigGeo : FusedDec<N> {
     static constexpr int WPS = N >= 16384 ? (PSDK_BIG16K_VT == 2 ? 2 : 4) : BIG_WAVES_PER_SIMD;
     static constexpr int BLOCKS_PER_CU = (4 * WPS / WAVES) > 0 ? (4 * WPS / WAVES) : 1;
     static constexpr int SCR = 2 * T::FRAME;
-    static_assert(FusedDec<N>::END <= SCR && FusedDec<N>::WEND <= SCR, "decimator arrays exceed the frame");
-    static_assert(THREADS >= FusedDec<N>::HIST, "one carried filter-state element per thread at most");
+    static_assert(FusedDec<N, NOX>::END <= SCR && FusedDec<N, NOX>::WEND <= SCR, "decimator arrays exceed the frame");
+    static_assert(THREADS >= FusedDec<N, NOX>::HIST, "one carried filter-state element per thread at most");
 };
+#ifndef PSDK_REGA
+#define PSDK_REGA 1
+#endif
 
 // DETREND / EWMA as in fused.hip.  Built for four wavefronts per SIMD (two at N = 16384, whose one
 // workgroup per CU is all the LDS holds).
@@ -81,13 +84,15 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                                                                          const cf *__restrict__ tw0g,
                                                                          const cf *__restrict__ twag)
 {
-    using G = BigGeo<N>;
+    // stage A of the decimator from registers + scalar-loaded boundary samples (see pair_step); f32 streams only
+    constexpr bool REGA = PSDK_REGA != 0 && !FRAMES && BigGeo<N>::VT == 1 && !(PSDK_ABL & 1024);
+    using G = BigGeo<N, REGA>;
     using T = BlockFft<N>;
     constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
     __shared__ cf s_frame[T::FRAME];
     __shared__ cf s_twb[T::TWB_SIZE];
     __shared__ float s_hist[G::HIST];
-    __shared__ float s_red[2 * G::WAVES + 4];
+    __shared__ __attribute__((aligned(8))) float s_red[2 * G::WAVES + 4];
 
     const int tp = threadIdx.x; // lane v of this thread is tl = tp + THREADS v
     for (int i = tp; i < T::TWB_SIZE; i += THREADS) { // [(q-1)][s]: W_SA^(s q)
@@ -312,6 +317,31 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     unsigned long long bst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
+    // REGA: the boundary samples of the four pieces stage A consumes in pair p (see there), scalar loads into SGPRs; issued
+    // a pass ahead (the start of pass C of the pair before) so that nothing waits for them
+#ifndef PSDK_REGA_PREFETCH
+#define PSDK_REGA_PREFETCH 1
+#endif
+    float halo[4][7];
+    auto load_halo = [&](int p) {
+        typedef const float __attribute__((address_space(4))) *kptr;
+        const int wv = __builtin_amdgcn_readfirstlane(tp >> 6);
+        const float *hb = job.src + (size_t)p * N + N / 2 + 256 * wv; // this wavefront's first sample of piece 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            kptr h = (kptr)(hb + r * (N / 4));
+            halo[r][0] = h[-4]; // the lane below lane 0: x, y, z, w
+            halo[r][1] = h[-3];
+            halo[r][2] = h[-2];
+            halo[r][3] = h[-1];
+            halo[r][4] = h[-7]; // two below: y, w
+            halo[r][5] = h[-5];
+            halo[r][6] = h[-9]; // three below: w
+        }
+    };
+    if constexpr (REGA && PSDK_REGA_PREFETCH != 0)
+        load_halo(p0);
+
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
     auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, unsigned snext,
                          bool more, float *o, int p) {
@@ -350,6 +380,38 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::XO + h] = x.y;
             sf[G::XO + h + 1] = x.w;
         };
+        if constexpr (REGA) {
+            // Stage A straight from the registers the loads filled, as fused.hip does for its one-wavefront team: lane tl
+            // holds samples 4 tl .. 4 tl + 3 of each N/4-sample piece and takes the three lanes below with DPP wavefront
+            // shifts.  Here the lanes below lane 0 belong to ANOTHER wavefront (or, for the first wavefront, to the piece
+            // before): the seven samples of theirs that lanes 0..2 need -- x[-4..-1], x[-7], x[-5], x[-9] counted from the
+            // wavefront's first sample -- are wavefront-uniform, so they come as SCALAR loads from the stream (constant
+            // address space: lines the neighbouring wavefront's vector loads brought into L2 a pair ago) and enter the
+            // shifts as the fill of lane 0.  No polyphase sample arrays, no LDS reads on the input side of the stage and
+            // one workgroup barrier fewer per pair.
+            const float4 *pc[4] = {&up[0][0], &up[0][1], &nl[0][0], &nl[0][1]};
+            if constexpr (PSDK_REGA_PREFETCH == 0)
+                load_halo(p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 &cu = *pc[r];
+                const float s1x = dpp_shr1(halo[r][0], cu.x), s1y = dpp_shr1(halo[r][1], cu.y);
+                const float s1z = dpp_shr1(halo[r][2], cu.z), s1w = dpp_shr1(halo[r][3], cu.w);
+                const float s2y = dpp_shr1(halo[r][4], s1y), s2w = dpp_shr1(halo[r][5], s1w);
+                const float s3w = dpp_shr1(halo[r][6], s2w);
+                // out j = xe[j-2] + t0 (xo[j-5] + xo[j]) + t1 (xo[j-4] + xo[j-1]) + t2 (xo[j-3] + xo[j-2])   (fused.hip)
+                float a0 = 0.0f, a1 = 0.0f;
+                a0 += (s3w + cu.y) * ta[0];
+                a1 += (s2y + cu.w) * ta[0];
+                a0 += (s2y + s1w) * ta[1];
+                a1 += (s2w + cu.y) * ta[1];
+                a0 += (s2w + s1y) * ta[2];
+                a1 += (s1y + s1w) * ta[2];
+                const int u = tp + THREADS * r;
+                sf[G::AE + 11 + u] = s1x + a0;
+                sf[G::AO + 11 + u] = s1z + a1;
+            }
+        } else {
         if constexpr (!(PSDK_ABL & 1024)) {
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
@@ -379,6 +441,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sf[G::AE + 11 + u] = y0;
             sf[G::AO + 11 + u] = y1;
         }
+        } // !REGA
         __syncthreads();
         PSDK_BSTAMP(2); // stage A + barrier
 #pragma unroll
@@ -460,12 +523,10 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             sb = span_slope(ob, s_red[3], N);
         }
         if constexpr (DETREND == 3) { // (s_red is next written a pair later, several barriers on)
-            float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < G::WAVES; ++w) {
-                s1 += s_red[4 + 2 * w];
-                s2 += s_red[5 + 2 * w];
-            }
+            // the wavefronts' partial sums: lane l reads those of wavefront l mod WAVES (one 8-byte read) and the group of
+            // WAVES lanes adds them up with DPP -- a loop over s_red is 2 WAVES LDS reads a lane (32 at N = 16384)
+            const f2 tw_ = ld2(s_red + 4 + 2 * (tp & (G::WAVES - 1)));
+            const float s1 = group_sum<G::WAVES>(tw_.x), s2 = group_sum<G::WAVES>(tw_.y);
             ob = piv;
             ma = (s0c + s1) * (1.0f / (float)N);
             mb = (s1 + s2) * (1.0f / (float)N);
@@ -561,6 +622,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         if constexpr (!(PSDK_ABL & 512))
         PSDK_FFT_BARRIER();
         PSDK_BSTAMP(7); // pass B + barrier
+        if constexpr (REGA && PSDK_REGA_PREFETCH != 0)
+            load_halo(more ? p + 1 : p);
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             if constexpr (!(PSDK_ABL & 512))

@@ -20,11 +20,15 @@ namespace psdk {
 // new ones come from registers).  History sizes are chosen so that the polyphase offsets are
 // the same as in a stateless block with a 288-sample halo, which is what the warm-up at the
 // start of a run evaluates.
-template <int N>
+// NOX: no polyphase sample arrays (stage A reads the stream from registers): the A and B arrays start at 0, and at
+// N = 16384 every decimator address then fits the 16-bit DS offset field -- with the sample arrays in front, the A and B
+// arrays sat above 64 KiB, each access needed a base register of its own and the compiler spilled thirteen of them,
+// reloaded (vmcnt(0)!) inside every pair.
+template <int N, bool NOX = false>
 struct FusedDec {
     static constexpr int HX = 12, HA = 22, HB = 58;
     static constexpr int XE = 0, XO = XE + HX / 2 + N / 2;
-    static constexpr int AE = XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
+    static constexpr int AE = NOX ? 0 : XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
     static constexpr int BE = AO + 12 + N / 4, BO = BE + 30 + N / 8;
     static constexpr int END = BO + 30 + N / 8;
     static constexpr int HIST = HA + HB; // [0,11) AE, [11,22) AO, [22,51) BE, [51,80) BO
@@ -95,6 +99,25 @@ __device__ __forceinline__ float row_sum16(float v)
     v += PSDK_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
     v += PSDK_DPP(v, 0x141); // row_half_mirror
     v += PSDK_DPP(v, 0x140); // row_mirror
+#undef PSDK_DPP
+    return v;
+}
+// Sum over aligned groups of W lanes (W = 2, 4, 8, 16), every lane of a group receiving the group's sum (the first
+// log2 W steps of row_sum16).
+template <int W>
+__device__ __forceinline__ float group_sum(float v)
+{
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "group of lanes within a row");
+#define PSDK_DPP(x, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
+    if constexpr (W >= 2)
+        v += PSDK_DPP(v, 0xB1); // quad_perm [1,0,3,2]
+    if constexpr (W >= 4)
+        v += PSDK_DPP(v, 0x4E); // quad_perm [2,3,0,1]
+    if constexpr (W >= 8)
+        v += PSDK_DPP(v, 0x141); // row_half_mirror
+    if constexpr (W >= 16)
+        v += PSDK_DPP(v, 0x140); // row_mirror
 #undef PSDK_DPP
     return v;
 }
