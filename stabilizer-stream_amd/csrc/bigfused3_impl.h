@@ -274,8 +274,12 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         }
         // ---- decimator ---------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
-        if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            sf[h_pack & 0xFFFFu] = hs[tp];
+        // (an opaque asm on the packed slot per pair, so that the two unpacked LDS addresses are not kept -- and spilled -- as
+        // loop invariants, measured 3-6 % SLOWER at N = 8192: the packed word itself is then what gets reloaded, behind a
+        // vmcnt(0) at the top of the pair)
+        const unsigned hpk = h_pack;
+        if ((hpk & 0xFFFFu) != 0xFFFFu)
+            sf[hpk & 0xFFFFu] = hs[tp];
         {
             // samples -> polyphase arrays: sample tl + H j of a half chunk is even / odd with tl (H is even); new sample i sits
             // at [HX/2 + i/2] of its array, the 12 samples before the new ones (the end of chunk p's lower half) in front
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         __syncthreads();
         f2 yc; // stage C: N/8 outputs, two per lane; stored further down
         hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tp, tc, yc.x, yc.y);
-        if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            hs[tp] = sf[h_pack >> 16];
+        if ((hpk & 0xFFFFu) != 0xFFFFu)
+            hs[tp] = sf[hpk >> 16];
         __builtin_amdgcn_s_setprio(0);
 
         // ---- detrend parameters ------------------------------------------------------------

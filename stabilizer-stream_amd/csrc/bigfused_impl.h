@@ -370,8 +370,12 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
-        if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            sf[h_pack & 0xFFFFu] = hs[tp];
+        // (an opaque asm on the packed slot per pair, so that the two unpacked LDS addresses are not kept -- and spilled -- as
+        // loop invariants, measured 3-6 % SLOWER at N = 8192: the packed word itself is then what gets reloaded, behind a
+        // vmcnt(0) at the top of the pair)
+        const unsigned hpk = h_pack;
+        if ((hpk & 0xFFFFu) != 0xFFFFu)
+            sf[hpk & 0xFFFFu] = hs[tp];
         // samples -> polyphase arrays as single floats (ds_write2_b32 from the registers the loads
         // filled; an 8-byte store of {x, z} would cost moves right behind the loads)
         auto split = [&](int h, const float4 &x) {
@@ -460,8 +464,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             const int u = tp + THREADS * r;
             hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * u, tc, yc[r].x, yc[r].y);
         }
-        if ((h_pack & 0xFFFFu) != 0xFFFFu)
-            hs[tp] = sf[h_pack >> 16];
+        if ((hpk & 0xFFFFu) != 0xFFFFu)
+            hs[tp] = sf[hpk >> 16];
 
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(0);
