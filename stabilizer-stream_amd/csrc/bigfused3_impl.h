@@ -12,6 +12,12 @@
 #include "frames.h"
 #include "fused_common.h"
 
+#ifdef PSDK_ABL
+#define PSDK_ABL3 PSDK_ABL
+#else
+#define PSDK_ABL3 0
+#endif
+
 namespace psdk {
 
 template <int N>
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             float w[16]; // the window of this lane: one batch of coalesced loads (L2 resident)
 #pragma unroll
             for (int m = 0; m < 16; ++m)
-                w[m] = winp[tp + (N / 16) * m];
+                w[m] = (PSDK_ABL3 & 2048) ? 0.5f + dp.ea * (float)m : winp[tp + (N / 16) * m]; // (2048: timing only, no window loads)
             window_pair3<N, DETREND, EWMA>(vv, tp, lo, up, nl, w, dp);
         }
         {

@@ -550,13 +550,19 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one
         // exposed L2 round trip per pair where reading all table entries at their uses was nineteen.  (Issuing the
         // batch before the decimator instead hides that one as well but keeps 26 more registers live across it:
-        // measured slower at every size, and much slower at N = 16384, whose 1024 threads spill.)
+        // measured slower at every size, and much slower at N = 16384, whose 1024 threads spill.  The window alone in front of
+        // stage C, round 3: N = 8192 -2.7 %, Mean -10 %; N = 16384 +-0, Mean -12 % -- spills again.)
         typename T::Seeds sd[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
             const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
-            const float4 wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
+            float4 wq0, wq1, wq2, wq3;
+            if constexpr (PSDK_ABL & 2048) { // timing only: no window loads
+                wq0 = wq1 = wq2 = wq3 = make_float4(0.5f, 0.25f + dp.ea, 0.125f, 0.75f);
+            } else {
+                wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
+            }
             if constexpr (PSDK_HOIST_SEEDS != 0) {
                 sd[v] = sd_run[v];
                 // (opaque per pair: the products formed from the seeds must not be hoisted out of the loop with them --

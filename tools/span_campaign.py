@@ -15,6 +15,7 @@ pkg, ora = entry.load_package(), entry.load_oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 sizes = [64, 256, 512, 1024, 1024, 2048, 4096, 8192, 16384]
+sizes = [int(v) for v in os.environ.get("FUZZ_SIZES", "").split(",") if v] or sizes  # e.g. FUZZ_SIZES=8192,16384
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):

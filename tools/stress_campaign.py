@@ -11,6 +11,7 @@ pkg, ora = entry.load_package(), entry.load_oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 sizes = [64, 256, 512, 1024, 1024, 2048, 4096, 8192, 16384]
+sizes = [int(v) for v in os.environ.get("FUZZ_SIZES", "").split(",") if v] or sizes  # e.g. FUZZ_SIZES=8192,16384
 bad = 0
 t0 = time.time()
 fn = getattr(T.test_randomized_feed_stress, "__wrapped__", T.test_randomized_feed_stress)
