@@ -300,21 +300,23 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, two per step
+        for (int r = 0; r < 2; ++r) { // stage A: N/2 outputs, four per step
             const int u = tp + THREADS * r;
-            float y0, y1;
-            hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
-            sf[G::AE + 11 + u] = y0;
-            sf[G::AO + 11 + u] = y1;
+            float y[4];
+            hbf_four<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
+            sf[G::AE + 11 + 2 * u] = y[0];
+            sf[G::AO + 11 + 2 * u] = y[1];
+            sf[G::AE + 12 + 2 * u] = y[2];
+            sf[G::AO + 12 + 2 * u] = y[3];
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { // stage B: N/4 outputs
-            const int u = tp + THREADS * r;
-            float y0, y1;
-            hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 2 * u, tb, y0, y1);
-            sf[G::BE + 29 + u] = y0;
-            sf[G::BO + 29 + u] = y1;
+        { // stage B: N/4 outputs, four per lane
+            float y[4];
+            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * tp, tb, y);
+            sf[G::BE + 29 + 2 * tp] = y[0];
+            sf[G::BO + 29 + 2 * tp] = y[1];
+            sf[G::BE + 30 + 2 * tp] = y[2];
+            sf[G::BO + 30 + 2 * tp] = y[3];
         }
         __syncthreads();
         f2 yc; // stage C: N/8 outputs, two per lane; stored further down

@@ -24,8 +24,8 @@ namespace psdk {
 #define PSDK_FFT_BARRIER() __syncthreads()
 #endif
 // more TIMING-ONLY ablations (wrong results): 512 = pass B without its exchange (its butterflies on the registers pass A left:
-// the cost of a three-pass (16, 16, 16) plan); 1024 = stage A without LDS on its input side (no polyphase sample arrays, no
-// reads: what a register / DPP stage A would leave, minus its moves)
+// the cost of a three-pass (16, 16, 16) plan); 2048 = no window loads.  (1024, stage A without LDS on its input side, became
+// the real thing: REGA below.)
 #ifndef PSDK_ABL
 #define PSDK_ABL 0
 #endif
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                                                                          const cf *__restrict__ twag)
 {
     // stage A of the decimator from registers + scalar-loaded boundary samples (see pair_step); f32 streams only
-    constexpr bool REGA = PSDK_REGA != 0 && !FRAMES && BigGeo<N>::VT == 1 && !(PSDK_ABL & 1024);
+    constexpr bool REGA = PSDK_REGA != 0 && !FRAMES && BigGeo<N>::VT == 1;
     using G = BigGeo<N, REGA>;
     using T = BlockFft<N>;
     constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 sf[G::AO + 11 + u] = s1z + a1;
             }
         } else {
-        if constexpr (!(PSDK_ABL & 1024)) {
+        {
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const int tl = tp + THREADS * v;
@@ -432,29 +432,27 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         }
         PSDK_BSTAMP(1); // state + samples -> LDS (waits for the look-ahead loads) + barrier
 #pragma unroll
-        for (int r = 0; r < 4 * VT; ++r) { // stage A: N/2 outputs, two per step
+        for (int r = 0; r < 2 * VT; ++r) { // stage A: N/2 outputs, four per step
             const int u = tp + THREADS * r;
-            float y0, y1;
-            if constexpr (PSDK_ABL & 1024) {
-                const float4 &a = r == 0 ? up[0][0] : r == 1 ? up[0][1] : r == 2 ? nl[0][0] : nl[0][1];
-                const float4 &b = r == 0 ? lo[0][1] : r == 1 ? up[0][0] : r == 2 ? up[0][1] : nl[0][0];
-                y0 = a.x + (a.y + b.w) * ta[0] + (b.y + a.w) * ta[1] + (b.z + a.z) * ta[2] + b.x;
-                y1 = a.z + (a.w + b.y) * ta[0] + (b.w + a.y) * ta[1] + (b.x + a.x) * ta[2] + b.z;
-            } else
-            hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
-            sf[G::AE + 11 + u] = y0;
-            sf[G::AO + 11 + u] = y1;
+            float y[4];
+            hbf_four<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
+            sf[G::AE + 11 + 2 * u] = y[0];
+            sf[G::AO + 11 + 2 * u] = y[1];
+            sf[G::AE + 12 + 2 * u] = y[2];
+            sf[G::AO + 12 + 2 * u] = y[3];
         }
         } // !REGA
         __syncthreads();
         PSDK_BSTAMP(2); // stage A + barrier
 #pragma unroll
-        for (int r = 0; r < 2 * VT; ++r) { // stage B: N/4 outputs
+        for (int r = 0; r < VT; ++r) { // stage B: N/4 outputs, four per lane
             const int u = tp + THREADS * r;
-            float y0, y1;
-            hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 2 * u, tb, y0, y1);
-            sf[G::BE + 29 + u] = y0;
-            sf[G::BO + 29 + u] = y1;
+            float y[4];
+            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * u, tb, y);
+            sf[G::BE + 29 + 2 * u] = y[0];
+            sf[G::BO + 29 + 2 * u] = y[1];
+            sf[G::BE + 30 + 2 * u] = y[2];
+            sf[G::BO + 30 + 2 * u] = y[3];
         }
         __syncthreads();
         PSDK_BSTAMP(3); // stage B + barrier

@@ -398,23 +398,25 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             wave_sync();
             PSDK_STAMP(1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { // stage A: N/2 outputs, (2u, 2u+1) -> AE/AO[11 + u]
+            for (int r = 0; r < 2; ++r) { // stage A: N/2 outputs, (4u .. 4u+3) -> AE/AO[11 + 2u, + 1]
                 const int u = tl + TEAM * r;
-                float y0, y1;
-                hbf_two<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 2 * u, ta, y0, y1);
-                sf[G::AE + 11 + u] = y0;
-                sf[G::AO + 11 + u] = y1;
+                float y[4];
+                hbf_four<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
+                sf[G::AE + 11 + 2 * u] = y[0];
+                sf[G::AO + 11 + 2 * u] = y[1];
+                sf[G::AE + 12 + 2 * u] = y[2];
+                sf[G::AO + 12 + 2 * u] = y[3];
             }
         }
         wave_sync();
         PSDK_STAMP(2);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { // stage B: N/4 outputs -> BE/BO[29 + u]
-            const int u = tl + TEAM * r;
-            float y0, y1;
-            hbf_two<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 2 * u, tb, y0, y1);
-            sf[G::BE + 29 + u] = y0;
-            sf[G::BO + 29 + u] = y1;
+        { // stage B: N/4 outputs, four per lane (hbf_four) -> BE/BO[29 + 2 tl, + 1]
+            float y[4];
+            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * tl, tb, y);
+            sf[G::BE + 29 + 2 * tl] = y[0];
+            sf[G::BO + 29 + 2 * tl] = y[1];
+            sf[G::BE + 30 + 2 * tl] = y[2];
+            sf[G::BO + 30 + 2 * tl] = y[3];
         }
         wave_sync();
         PSDK_STAMP(3);

@@ -178,6 +178,43 @@ __device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const floa
     y1 = e1 + a1;
 }
 
+// four consecutive outputs (j .. j+3), j even: the same sums in the same order as two hbf_two calls, but the 2M + 3 inputs the
+// four share are read once -- M + 2 (+1) eight-byte reads for four outputs where two calls make 2 (M + 1).  The decimator
+// stages are the LDS-heavier half of a pair (more read instructions than the FFT's two exchanges).
+template <int M, int CE, int CO>
+__device__ __forceinline__ void hbf_four(const float *__restrict__ ev, const float *__restrict__ od, int j,
+                                         const float (&taps)[M], float (&y)[4])
+{
+    constexpr int LO = CO & ~1;
+    constexpr int CNT = (CO - LO) + 2 * M + 3;
+    constexpr int NP = (CNT + 1) / 2;
+    float w[2 * NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const f2 v = ld2(od + j + LO + 2 * k);
+        w[2 * k] = v.x;
+        w[2 * k + 1] = v.y;
+    }
+    constexpr int O = CO - LO;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            a[t] += (w[O + t + i] + w[O + t + 2 * M - 1 - i]) * taps[i];
+    float e[4];
+    if constexpr ((CE & 1) == 0) {
+        const f2 e01 = ld2(ev + j + CE), e23 = ld2(ev + j + CE + 2);
+        e[0] = e01.x, e[1] = e01.y, e[2] = e23.x, e[3] = e23.y;
+    } else {
+        const f2 e12 = ld2(ev + j + CE + 1);
+        e[0] = ev[j + CE], e[1] = e12.x, e[2] = e12.y, e[3] = ev[j + CE + 3];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        y[t] = e[t] + a[t];
+}
+
 __device__ __forceinline__ float fused_ewma_amp(const FusedJob &job, int step)
 {
     // sqrt of W_step = gamma^max(0, nb - max(step, i_s - 1))  (plan.h)
