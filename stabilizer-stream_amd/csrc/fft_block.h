@@ -158,6 +158,15 @@ struct BlockFft {
     static PSDK_HD void passB(int tl, cf *v, const cf *twb)
     {
         const int s = tl & 15;
+#if PSDK_TW_ROWS
+        if constexpr (PSDK_TW_ROWS & 2) {
+#pragma unroll
+            for (int i = 0; i < NBB; ++i)
+                Dft<RB>::run(v + RB * i);
+            twiddle_rows<RB, NBB>(v, twb + s);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NBB; ++i) {
             Dft<RB>::run(v + RB * i);

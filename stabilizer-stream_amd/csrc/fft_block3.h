@@ -78,6 +78,15 @@ struct BlockFft3 {
     static PSDK_HD void pass1(int tl, cf *v, const cf *tw1)
     {
         const int s = tl & 15;
+#if PSDK_TW_ROWS
+        if constexpr (PSDK_TW_ROWS & 4) {
+#pragma unroll
+            for (int i = 0; i < NB1; ++i)
+                Dft<R1>::run(v + R1 * i);
+            twiddle_rows<R1, NB1>(v, tw1 + s);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NB1; ++i) {
             Dft<R1>::run(v + R1 * i);

@@ -40,6 +40,36 @@ PSDK_HD cf lds_ld(const cf *p)
 #endif
 }
 
+// The inter-pass twiddles of a radix-R pass held in an LDS table tw[(q - 1) * 16 + s] (q = 1 .. R - 1): applied to the NB
+// butterflies of a lane, v[R i + q] *= tw_q, reading the table as SINGLE 8-byte reads in batches of B that are in flight
+// together.  Left to the compiler the reads pair up as ds_read2_b64 (8 LDS cycles for 16 bytes a lane where two ds_read_b64
+// take 2 + 2); read one at a time through lds_ld right where they are used they serialise on one register pair.  Batches of
+// five measured +1 % at N = 1024 (eight: +1.3 %, but -0.6 % with Mean, whose registers are tighter).
+#ifndef PSDK_TW_BATCH
+#define PSDK_TW_BATCH 5
+#endif
+#ifndef PSDK_TW_ROWS // bit 0: team FFT (N = 1024), bit 1: workgroup FFT pass B, bit 2: three-pass workgroup FFT pass 1
+#define PSDK_TW_ROWS 1
+#endif
+template <int R, int NB, int B = PSDK_TW_BATCH>
+PSDK_HD void twiddle_rows(cf *v, const cf *tw_s)
+{
+#pragma unroll
+    for (int q0 = 1; q0 < R; q0 += B) {
+        cf t[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (q0 + k < R)
+                t[k] = lds_ld(tw_s + (q0 + k - 1) * 16);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int k = 0; k < B; ++k)
+                if (q0 + k < R)
+                    v[R * i + q0 + k] = cmul(v[R * i + q0 + k], t[k]);
+    }
+}
+
 // Span detrend (src/psd.rs:94-102): slope (x[N-1] - x[0]) / (N - 1) as an unevaluated sum hi + lo.
 // A slope rounded to f32 leaves a ramp error of up to D 2^-24 at the end of the segment, coherent over
 // the segment: in the lowest bins that is ~1e-5 of the power at N >= 8192 (D = the span, a few sigma).

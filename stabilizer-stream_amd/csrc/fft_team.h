@@ -84,6 +84,13 @@ struct TeamFft {
     static PSDK_HD void pass1(int tl, cf *v, const cf *tw1)
     {
         const int s = tl & 15;
+#if PSDK_TW_ROWS
+        if constexpr (NB1 == 1) { // (measured per size: see twiddle_rows in fft_core.h)
+            Dft<R1>::run(v);
+            twiddle_rows<R1, 1>(v, tw1 + s);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NB1; ++i) {
             Dft<R1>::run(v + R1 * i);
