@@ -445,7 +445,8 @@ def main():
         alg_bps = (fr_size / (FR_BATCHES * 8.0 * 4.0)) if frames else ALG_BYTES_PER_SAMPLE
         ach = alg_bps * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
-        kname = "fused_kernel" if n in (256, 512, 1024) else ("bigfused_kernel" if n <= 16384 and n >= 2048 else "welch_kernel")
+        kname = ("fused_kernel" if n in (256, 512, 1024) else "bigfused3_kernel" if n in (2048, 4096) else
+                 "bigfused_kernel" if n in (8192, 16384) else "welch_kernel")
         tr = measured_traffic(kname, n, C, T)
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, %s)" % (n, "AdcDac frames, samples of the four traces" if frames else "raw f32"),

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     using G = Big3Geo<N>;
     using T = BlockFft3<N>;
     constexpr int TEAM = G::TEAM, THREADS = G::THREADS, H = G::H;
-    __shared__ cf s_frame[T::FRAME];
+    __shared__ __attribute__((aligned(16))) cf s_frame[T::FRAME];
     __shared__ cf s_tw1[T::TW1_SIZE];
     __shared__ float s_hist[G::HIST];
     __shared__ __attribute__((aligned(8))) float s_red[2 * G::WAVES + 4];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         __syncthreads();
         { // stage B: N/4 outputs, four per lane
             float y[4];
-            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * tp, tb, y);
+            hbf_four<HBF_MB, G::B_CE, G::B_CO, PSDK_HBF_WIDE != 0 && (G::AO % 4 == 0)>(sf + G::AE, sf + G::AO, 4 * tp, tb, y);
             sf[G::BE + 29 + 2 * tp] = y[0];
             sf[G::BO + 29 + 2 * tp] = y[1];
             sf[G::BE + 30 + 2 * tp] = y[2];

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     using G = BigGeo<N, REGA>;
     using T = BlockFft<N>;
     constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
-    __shared__ cf s_frame[T::FRAME];
+    __shared__ __attribute__((aligned(16))) cf s_frame[T::FRAME];
     __shared__ cf s_twb[T::TWB_SIZE];
     __shared__ float s_hist[G::HIST];
     __shared__ __attribute__((aligned(8))) float s_red[2 * G::WAVES + 4];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         for (int r = 0; r < VT; ++r) { // stage B: N/4 outputs, four per lane
             const int u = tp + THREADS * r;
             float y[4];
-            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * u, tb, y);
+            hbf_four<HBF_MB, G::B_CE, G::B_CO, PSDK_HBF_WIDE != 0 && (G::AO % 4 == 0)>(sf + G::AE, sf + G::AO, 4 * u, tb, y);
             sf[G::BE + 29 + 2 * u] = y[0];
             sf[G::BO + 29 + 2 * u] = y[1];
             sf[G::BE + 30 + 2 * u] = y[2];

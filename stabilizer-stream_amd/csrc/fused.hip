@@ -106,7 +106,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     using G = FusedGeo<N>;
     using T = TeamFft<N>;
     constexpr int TEAM = G::TEAM, TPW = G::TPW, TEAMS = G::TEAMS;
-    __shared__ cf s_frames[TEAMS * T::FRAME];
+    __shared__ __attribute__((aligned(16))) cf s_frames[TEAMS * T::FRAME];
     __shared__ cf s_tw0[T::TW0_SIZE];
     __shared__ cf s_tw1[T::TW1_SIZE > 0 ? T::TW1_SIZE : 1];
     __shared__ float4 s_win[N / 4]; // window: float4 piece m of team-lane tl at [TEAM m + tl]
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         PSDK_STAMP(2);
         { // stage B: N/4 outputs, four per lane (hbf_four) -> BE/BO[29 + 2 tl, + 1]
             float y[4];
-            hbf_four<HBF_MB, G::B_CE, G::B_CO>(sf + G::AE, sf + G::AO, 4 * tl, tb, y);
+            hbf_four<HBF_MB, G::B_CE, G::B_CO, PSDK_HBF_WIDE != 0 && (G::AO % 4 == 0)>(sf + G::AE, sf + G::AO, 4 * tl, tb, y);
             sf[G::BE + 29 + 2 * tl] = y[0];
             sf[G::BO + 29 + 2 * tl] = y[1];
             sf[G::BE + 30 + 2 * tl] = y[2];

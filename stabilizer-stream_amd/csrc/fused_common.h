@@ -8,6 +8,9 @@
 #include "hbf_taps.h"
 #include "kernels.h"
 
+#ifndef PSDK_HBF_WIDE
+#define PSDK_HBF_WIDE 1 // stage B's shared inputs as 16-byte LDS reads (hbf_four)
+#endif
 #ifndef PSDK_DEC_PRIO
 #define PSDK_DEC_PRIO 3 // wave priority during the decimator stages (0 during the FFT)
 #endif
@@ -181,19 +184,31 @@ __device__ __forceinline__ void hbf_two(const float *__restrict__ ev, const floa
 // four consecutive outputs (j .. j+3), j even: the same sums in the same order as two hbf_two calls, but the 2M + 3 inputs the
 // four share are read once -- M + 2 (+1) eight-byte reads for four outputs where two calls make 2 (M + 1).  The decimator
 // stages are the LDS-heavier half of a pair (more read instructions than the FFT's two exchanges).
-template <int M, int CE, int CO>
+// WIDE: od + j + (CO & ~3) is 16-byte aligned (j a multiple of 4, the array's offset in the frame too): the shared inputs
+// are read as ds_read_b128 -- lanes 16 bytes apart are conflict-free for 16-byte reads (4 x 16 lanes), while 8-byte reads at
+// that stride are 2-way bank conflicts (2 x 32 lanes over 128 dwords), which gives back what the shared reads save.
+template <int M, int CE, int CO, bool WIDE = false>
 __device__ __forceinline__ void hbf_four(const float *__restrict__ ev, const float *__restrict__ od, int j,
                                          const float (&taps)[M], float (&y)[4])
 {
-    constexpr int LO = CO & ~1;
+    constexpr int LO = WIDE ? (CO & ~3) : (CO & ~1);
     constexpr int CNT = (CO - LO) + 2 * M + 3;
-    constexpr int NP = (CNT + 1) / 2;
+    constexpr int NP = WIDE ? 2 * ((CNT + 3) / 4) : (CNT + 1) / 2;
     float w[2 * NP];
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const f2 v = ld2(od + j + LO + 2 * k);
-        w[2 * k] = v.x;
-        w[2 * k + 1] = v.y;
+        for (int k = 0; k < NP / 2; ++k) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v v = *(const volatile __attribute__((address_space(3))) f4v *)(od + j + LO + 4 * k);
+            w[4 * k] = v.x, w[4 * k + 1] = v.y, w[4 * k + 2] = v.z, w[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const f2 v = ld2(od + j + LO + 2 * k);
+            w[2 * k] = v.x;
+            w[2 * k + 1] = v.y;
+        }
     }
     constexpr int O = CO - LO;
     float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
