@@ -64,7 +64,9 @@ __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__
     }
 }
 
-template <int N>
+// FR: the launch holds jobs whose stream is read in place from AdcDac frames (a runtime branch per load otherwise sat in
+// every launch: N = 128 lost 30 % to it)
+template <int N, bool FR = false>
 __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBatch batch,
                                                                   const float *__restrict__ win,
                                                                   const cf *__restrict__ tw)
@@ -106,7 +108,13 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
         const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
         const bool fr = job.fspan >= 0;
         const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
-        auto xa = [&](int j) { return fr ? frame_sample(fsp, job.fch, (unsigned long long)(ofs_a + job.s_off + j)) : job.src[ofs_a + j]; };
+        auto xa = [&](int j) {
+            if constexpr (FR) {
+                if (fr)
+                    return frame_sample(fsp, job.fch, (unsigned long long)(ofs_a + job.s_off + j));
+            }
+            return job.src[ofs_a + j];
+        };
         auto xb = [&](int j) { return xa(j + hop); };
 
         float ra[E], rb[E];
@@ -484,6 +492,7 @@ __device__ __forceinline__ float hbf_point(const float *__restrict__ ev, const f
     return ev[j + ce] + acc;
 }
 
+template <bool FR>
 __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
 {
     using namespace dec;
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
         const long long i0 = x0 + 2 * r;
         float e = 0.0f, o = 0.0f;
         if (i0 >= 0 && i0 + 1 < x_end) {
-            if (job.fspan >= 0) { // AdcDac frames read in place
+            if (FR && job.fspan >= 0) { // AdcDac frames read in place
                 const unsigned long long si = (unsigned long long)(i0 - job.src_base + job.s_off);
                 e = frame_sample(batch.fspans[job.fspan], job.fch, si);
                 o = frame_sample(batch.fspans[job.fspan], job.fch, si + 1);
@@ -833,11 +842,16 @@ hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *
     default:
         break;
     }
+    bool any_fr = false;
+    for (int j = 0; j < b.njobs; ++j)
+        any_fr = any_fr || b.jobs[j].fspan >= 0;
     switch (n) {
 #define PSDK_CASE(NN)                                                                            \
     case NN:                                                                                     \
-        hipLaunchKernelGGL(welch_kernel<NN>, dim3(b.nblocks), dim3(WelchCfg<NN>::BLOCK), 0, s, b, \
-                           win, tw);                                                             \
+        if (any_fr)                                                                              \
+            hipLaunchKernelGGL((welch_kernel<NN, true>), dim3(b.nblocks), dim3(WelchCfg<NN>::BLOCK), 0, s, b, win, tw); \
+        else                                                                                     \
+            hipLaunchKernelGGL((welch_kernel<NN, false>), dim3(b.nblocks), dim3(WelchCfg<NN>::BLOCK), 0, s, b, win, tw); \
         break;
         PSDK_CASE(16)
         PSDK_CASE(32)
@@ -861,7 +875,13 @@ hipError_t launch_dec(const DecBatch &b, hipStream_t s)
 {
     if (b.ntiles <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(hbf_dec8_kernel, dim3(b.ntiles), dim3(256), 0, s, b);
+    bool any_fr = false;
+    for (int j = 0; j < b.njobs; ++j)
+        any_fr = any_fr || b.jobs[j].fspan >= 0;
+    if (any_fr)
+        hipLaunchKernelGGL(hbf_dec8_kernel<true>, dim3(b.ntiles), dim3(256), 0, s, b);
+    else
+        hipLaunchKernelGGL(hbf_dec8_kernel<false>, dim3(b.ntiles), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
