@@ -249,6 +249,8 @@ def main():
                     help="samples per channel per pass = 2^this (default 26 at --gpus 1, 24 at --gpus > 1)")
     ap.add_argument("--channels-per-gpu", type=int, default=None, help="default 1 at --gpus 1, 8 at --gpus > 1 (config 4)")
     ap.add_argument("--detrend", default="none")
+    ap.add_argument("--window", default="hann", choices=["hann", "rectangular", "hamming"],
+                    help="hann (the configs'), rectangular (overlap 0: generic kernels) or a caller-built Hamming table with overlap N/2")
     ap.add_argument("--coalesce", type=int, default=None,
                     help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 8)")
     ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")
@@ -319,7 +321,17 @@ def main():
     pkg = entry.load_package()
     n, C = args.n, args.channels_per_gpu
     T = 1 << args.log2_batch
-    bank = pkg.PsdCascadeBank(n, C, device=local_rank)
+    def window_arg():
+        if args.window == "hann":
+            return pkg.Window.HANN
+        if args.window == "rectangular":
+            return pkg.Window.RECTANGULAR
+        i = np.arange(n, dtype=np.float64)  # a Window<N> built by the caller (src/psd.rs:12-20), overlap N/2
+        w = (0.54 - 0.46 * np.cos(2 * np.pi * i / n)).astype(np.float32)
+        m1, m2 = float(np.mean(w.astype(np.float64))), float(np.mean(w.astype(np.float64) ** 2))
+        return pkg.WindowTable(w, np.float32(m1 * m1).item(), np.float32(m2 / (m1 * m1)).item(), n // 2)
+
+    bank = pkg.PsdCascadeBank(n, C, device=local_rank, window=window_arg())
     bank.set_detrend(pkg.Detrend[args.detrend.upper()])
     if args.coalesce is not None:
         bank.configure(coalesce=args.coalesce)
@@ -367,7 +379,7 @@ def main():
 
     from stabilizer_stream_amd import shard
     if args.clock_warm_ms > 0:  # a scratch cascade: the measured one sees exactly W + K steps
-        scratch = pkg.PsdCascadeBank(n, C, device=local_rank)
+        scratch = pkg.PsdCascadeBank(n, C, device=local_rank, window=window_arg())
         scratch.set_detrend(pkg.Detrend[args.detrend.upper()])
         if args.coalesce is not None:
             scratch.configure(coalesce=args.coalesce)
@@ -457,7 +469,7 @@ def main():
             "config": {"workload": (f"BASELINE configs[2]: 4-trace AdcDac frames ({FR_BATCHES} batches, {fr_size} B) resident in HBM, read in place "
                                     f"(psdc_process_adcdac_frames_device): " if frames else "") +
                                    f"{'BASELINE configs[3]' if multi else 'BASELINE configs[1]'}: {C * world}-channel raw f32 stream "
-                                   f"({C} per GPU), PsdCascade N={n}, Hann, detrend {args.detrend}, a step = {P} passes over "
+                                   f"({C} per GPU), PsdCascade N={n}, {'Hann' if args.window == 'hann' else args.window}, detrend {args.detrend}, a step = {P} passes over "
                                    f"2^{args.log2_batch} samples/channel resident in HBM (the stream continues across passes), "
                                    f"{ns} stages instantiated ({reached} with count>=1)",
                        "fft_size": n, "channels": C * world, "channels_per_gpu": C,

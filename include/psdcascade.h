@@ -115,9 +115,10 @@ typedef struct psdc_profile {
  * window's overlap N/2 that is every multiple of 16).  Returns NULL on failure; psdc_last_error(NULL)
  * explains.
  * Which kernels run: the single-pass fused kernels (stream read once: detrend +
- * window + FFT + |X|^2 + /8 decimator in one launch) exist for the HANN window and
- * n = 256 ... 16384 (powers of two) -- what the reference's binaries and BASELINE configs use.  The
- * rectangular window, caller-built windows, n < 256 and sizes that are not powers of two take the generic
+ * window + FFT + |X|^2 + /8 decimator in one launch) exist for n = 256 ... 16384 (powers of two) and every window
+ * whose overlap is n / 2 -- the HANN window (what the reference's binaries and BASELINE configs use) and caller-built
+ * tables with that overlap; they read the table and assume only the hop.  The
+ * rectangular window, caller-built windows of another overlap, n < 256 and sizes that are not powers of two take the generic
  * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about a third of the rate;
  * sizes that are not powers of two evaluate the DFT in chirp-z form on a power-of-two transform of at
  * least twice the length: two such transforms per segment pair). */
@@ -129,8 +130,9 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
  * hop.  The reference asserts (n - overlap) % 8 == 0 when the first segment is decimated (src/psd.rs:246-247);
  * here that -- and overlap < n -- is checked at construction (PSDC_ERR_ARG through psdc_last_error(NULL)).
  * A table that compares equal, bit for bit and in its three constants, to Window::hann() or
- * Window::rectangular() is recognised as such (Hann keeps the single-pass fused kernels); any other table
- * runs the generic two-pass kernels (same results, about a third of the rate). */
+ * Window::rectangular() is recognised as such; any table with overlap == n / 2 (Hann, a caller's Hamming,
+ * Blackman, ...) runs the single-pass fused kernels, any other overlap the generic two-pass kernels (same
+ * results, about a third of the rate). */
 psdc_handle *psdc_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap,
                                 uint32_t n_channels, int device);
 

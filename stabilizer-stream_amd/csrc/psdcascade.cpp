@@ -677,6 +677,14 @@ bool device_idle(psdc_handle *h) { return !h->coalesce_always && hipStreamQuery(
 // costs two launches whatever the depth: a post launch (the seam copy of this round with the
 // deferred epilogue of the last one) and the fused launch (plus the generic welch / decimator
 // kernels when something does not fit a pair).
+// The fused single-pass kernels read the window from its table and assume nothing about it but a hop of N/2: Window::hann()
+// and every caller-built Window<N> with overlap N/2 (Hamming, Blackman, ... -- src/psd.rs:12-20 has pub fields) run on them;
+// other overlaps (rectangular: 0) take the generic two-pass kernels.
+static bool fused_window(const psdc_handle *h)
+{
+    return h->window_kind == PSDC_WINDOW_HANN || (h->window_kind == PSDC_WINDOW_CUSTOM && 2 * (uint64_t)h->geo.overlap == h->n);
+}
+
 // `all`: issue odd segments of decimated stages too (read-outs); the ingest path
 // leaves them for their partner.  *did_work tells whether anything was issued;
 // read-outs call rounds until idle.
@@ -684,7 +692,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
-    const bool fast_ok = fused_supported((int)h->n) && h->window_kind == PSDC_WINDOW_HANN;
+    const bool fast_ok = fused_supported((int)h->n) && fused_window(h);
     // fused runs rebuild their decimator state from the 288 samples before their first new
     // sample (which sits hop after the run's first segment start): samples needed in front of it
     const uint64_t need_pre = HBF_HALO > g.hop ? HBF_HALO - g.hop : 0;
@@ -2282,7 +2290,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
     if (good && batches > 0) {
         h->idle = false;
         const size_t per_frame = (size_t)batches * 8; // samples per trace and frame
-        const bool in_place_ok = fused_frames_supported((int)h->n) && h->window_kind == PSDC_WINDOW_HANN;
+        const bool in_place_ok = fused_frames_supported((int)h->n) && fused_window(h);
         // pieces of <= FSPAN_MAX_SAMPLES samples per trace (the kernels' cell arithmetic) / 2^24 on the decode path
         const size_t piece_frames = std::max<size_t>(1, (in_place_ok ? (size_t)FSPAN_MAX_SAMPLES : ((size_t)1 << 24)) / per_frame);
         for (size_t f0 = 0; f0 < good; f0 += piece_frames) {

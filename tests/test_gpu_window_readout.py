@@ -78,6 +78,61 @@ def test_cascade_with_caller_window(pkg, ora, gpu_required, n, detrend):
     g.close()
 
 
+def blackman(pkg, n):
+    """Another caller-built Window<N> with the usual Welch overlap of N/2."""
+    i = np.arange(n, dtype=np.float64)
+    w = (0.42 - 0.5 * np.cos(2 * np.pi * i / n) + 0.08 * np.cos(4 * np.pi * i / n)).astype(np.float32)
+    m1, m2 = float(np.mean(w.astype(np.float64))), float(np.mean(w.astype(np.float64) ** 2))
+    return pkg.WindowTable(w, np.float32(m1 * m1).item(), np.float32(m2 / (m1 * m1)).item(), n // 2)
+
+
+@pytest.mark.parametrize("n,detrend,make", [(256, "none", "hamming"), (512, "mean", "blackman"), (1024, "none", "hamming"),
+                                            (1024, "span", "blackman"), (2048, "midpoint", "hamming"), (4096, "none", "blackman"),
+                                            (4096, "mean", "hamming"), (8192, "none", "hamming"), (16384, "none", "blackman")])
+def test_caller_window_with_half_overlap_runs_the_fused_kernels(pkg, ora, gpu_required, n, detrend, make):
+    """A caller-built Window<N> whose overlap is N/2 (src/psd.rs:12-20: any table, any constants) takes the same single-pass
+    kernels as Window::hann() -- they read the table and assume only the hop: host-fed in odd chunks, device-fed in place,
+    finite averaging on a second handle, every stage and the stitched PSD against the oracle given the SAME table."""
+    import torch
+    win = hamming(pkg, n, n // 2) if make == "hamming" else blackman(pkg, n)
+    total = 1400 * n + 8 * 3
+    x = make_signal(pkg, total, seed=70 + n, tone=0.25, dc=0.3)
+    d = torch.from_numpy(x).cuda()
+    for avg in (None, (30, 2000)):
+        g = pkg.PsdCascadeBank(n, window=win)
+        assert g.window_get()[0] == pkg.Window.CUSTOM
+        g.set_detrend(pkg.Detrend[detrend.upper()])
+        a = pkg.AvgOpts(*avg) if avg else None
+        if a:
+            g.set_avg(a)
+        cut = 4 * ((total // 28) | 1)  # (16-byte aligned: the device span is read in place)
+        g.process(0, x[:5])
+        g.process(0, x[5:cut])
+        g.process_device(0, d.data_ptr() + 4 * cut, total - cut)
+        check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, avg=a, window=win.as_tuple(),
+                             what=f"{make} overlap N/2, N={n} {detrend} avg={avg}")
+        g.close()
+
+
+def test_caller_window_frames_in_place(pkg, ora, gpu_required):
+    """AdcDac frames read in place under a caller-built window (overlap N/2): same kernels, the caller's table."""
+    import torch
+    from test_gpu_frames_inplace import make_frames
+    n, batches = 4096, 22
+    win = hamming(pkg, n, n // 2)
+    nframes = (200 * n) // (batches * 8) + 11
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=77)
+    dd = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4, window=win)
+    half = nframes // 2
+    assert g.process_adcdac_frames_device(dd.data_ptr(), fs, half) == half
+    assert g.process_adcdac_frames_device(dd.data_ptr() + half * fs, fs, nframes - half) == nframes - half
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, channel=c, window=win.as_tuple(),
+                             what=f"frames in place, Hamming table, trace {c}")
+    g.close()
+
+
 @pytest.mark.parametrize("n", [256, 1024, 4096])
 def test_library_windows_passed_as_tables(pkg, ora, gpu_required, n):
     """Window::hann() / Window::rectangular() handed over as tables are recognised (Hann keeps the fused kernels)
