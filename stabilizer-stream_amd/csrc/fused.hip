@@ -50,7 +50,7 @@ __device__ unsigned long long g_stamps[16];
 
 // -DPSDK_ABL=<bits>: TIMING-ONLY ablations (wrong results; tools/build_variants.sh), never in the shipped build:
 //   1 no pass-1 twiddles   2 no carried-state copy in/out   4 no decimator   8 no FFT passes 1 and 2
-//   16 no stage A   32 no stage C   64 no look-ahead loads
+//   16 no stage A   32 no stage C   64 no look-ahead loads   128 stage C computed but not stored
 #ifndef PSDK_ABL
 #define PSDK_ABL 0
 #endif
@@ -423,7 +423,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         if constexpr (!(PSDK_ABL & 32)) { // stage C: N/8 outputs, two per lane, straight to the next stage's stream
             float y0, y1;
             hbf_two<HBF_MC, G::C_CE, G::C_CO>(sf + G::BE, sf + G::BO, 2 * tl, tc, y0, y1);
-            *reinterpret_cast<f2 *>(o + 2 * tl) = {y0, y1};
+            if ((PSDK_ABL & 1024) ? job.npairs >= 0 : (!(PSDK_ABL & 128) || job.npairs < 0)) { // (1024: the store under an always-true branch the compiler cannot see through) // (128: the stage is computed, its outputs are not stored -- what the inter-stage WRITE costs)
+                if constexpr (PSDK_ABL & 512) { // (512: a nontemporal store)
+                    __builtin_nontemporal_store(y0, o + 2 * tl);
+                    __builtin_nontemporal_store(y1, o + 2 * tl + 1);
+                } else {
+                    *reinterpret_cast<f2 *>(o + 2 * tl) = {y0, y1};
+                }
+            }
         }
         if constexpr (!(PSDK_ABL & 2)) {
 #pragma unroll
@@ -551,16 +558,20 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
 
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
+        if constexpr (PSDK_ABL & 2048) // (2048: the output stream rounded down to a 128-byte boundary -- what its alignment costs)
+            o = reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(o) & ~(uintptr_t)127);
         for (int i = 0; i < nrun; i += 2) {
             pair_step(ga, gb, gc, cp + N / 4, sp + N, i + 1 < nrun, o, p0 + i);
             cp += N / 4;
             sp += N;
-            o += N / 8;
+            if (!(PSDK_ABL & 256)) // (256: every pair of a run stores to the run's first N/8 outputs -- the store instructions without their traffic)
+                o += N / 8;
             if (i + 1 < nrun) {
                 pair_step(gc, gb, ga, cp + N / 4, sp + N, i + 2 < nrun, o, p0 + i + 1);
                 cp += N / 4;
                 sp += N;
-                o += N / 8;
+                if (!(PSDK_ABL & 256))
+                    o += N / 8;
             }
         }
     }
