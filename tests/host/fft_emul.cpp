@@ -321,20 +321,26 @@ static int check_block()
     for (int q = 0; q < 4; ++q)
         for (int c = 0; c < 4; ++c)
             wr_instr([&](int tl) { return 4 * tl + (tl >> 2) + T::STEP0 * q + c; });
+    long rd0 = rd, rdi0 = rdi;
     for (int i = 0; i < T::NBA; ++i)
         for (int m = 0; m < T::RA; ++m) {
             auto a = [&](int tl) { return T::baseA(tl) + T::STEP0 * (TEAM / T::SA) * i + T::STEPA * m; };
             rd_instr(a);
             wr_instr(a);
         }
+    if (getenv("FFT_EMUL_VERBOSE")) printf("   pass A reads %ld (ideal %ld)\n", rd - rd0, rdi - rdi0);
+    rd0 = rd, rdi0 = rdi;
     for (int i = 0; i < T::NBB; ++i)
         for (int m = 0; m < T::RB; ++m) {
             auto a = [&](int tl) { return T::baseB(tl) + T::STEPA * i + 17 * m; };
             rd_instr(a);
             wr_instr(a);
         }
+    if (getenv("FFT_EMUL_VERBOSE")) printf("   pass B reads %ld (ideal %ld)\n", rd - rd0, rdi - rdi0);
+    rd0 = rd, rdi0 = rdi;
     for (int m = 0; m < 16; ++m)
         rd_instr([&](int tl) { return 17 * tl + m; });
+    if (getenv("FFT_EMUL_VERBOSE")) printf("   pass C reads %ld (ideal %ld)\n", rd - rd0, rdi - rdi0);
     printf("block<%5d> (4,%2d,%2d,16): max|dP|/Pmax=%.3g  lds read cycles %ld (ideal %ld)  write cycles %ld (ideal %ld)\n",
            N, T::RA, T::RB, err, rd, rdi, wr, wri);
     return (err < 3e-6) ? 0 : 1;
