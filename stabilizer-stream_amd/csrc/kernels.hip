@@ -661,7 +661,11 @@ __global__ __launch_bounds__(256) void adcdac_kernel(const uint8_t *__restrict__
 // (wrapping_sub), acc[3] <- seq of frame 0 (low half) | seq + batches of the last (high half).  The workgroup that
 // finishes last (acc[4]: arrival ticket) copies the four words to `host_out` (pinned host memory) and zeroes acc for the
 // next call: one launch, no memset, no copy kernel -- the call sits on a side stream and the host waits for it alone.
-__global__ __launch_bounds__(256) void adcdac_verdict_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames,
+// One WAVEFRONT per workgroup: the launch runs beside a fused kernel whose workgroups hold every register of their SIMDs; the
+// slots the fused launch leaves free are whole fused workgroups (two wavefronts at N = 2048), and a single small wavefront fits
+// any of them, which a four-wavefront workgroup does not (N = 2048 frames did not overlap: 416 GS/s, one launch per call).
+constexpr int VERDICT_THREADS = 64;
+__global__ __launch_bounds__(VERDICT_THREADS) void adcdac_verdict_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames,
                                                              int batches, int payload_ok, int check, size_t n_loss,
                                                              unsigned long long *acc, unsigned long long *host_out)
 {
@@ -677,8 +681,8 @@ __global__ __launch_bounds__(256) void adcdac_verdict_kernel(const uint8_t *__re
                           (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24));
     };
     unsigned long long rec = 0, drop = 0, bad = 0;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t f0 = (size_t)blockIdx.x * 256 + threadIdx.x; f0 < n_frames; f0 += 4 * stride) {
+    const size_t stride = (size_t)gridDim.x * VERDICT_THREADS;
+    for (size_t f0 = (size_t)blockIdx.x * VERDICT_THREADS + threadIdx.x; f0 < n_frames; f0 += 4 * stride) {
         uint2 h[4], hp[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -717,28 +721,22 @@ __global__ __launch_bounds__(256) void adcdac_verdict_kernel(const uint8_t *__re
             }
         }
     }
-    __shared__ unsigned long long s_rec[256], s_drop[256], s_bad[256];
-    __shared__ int s_last;
-    s_rec[threadIdx.x] = rec;
-    s_drop[threadIdx.x] = drop;
-    s_bad[threadIdx.x] = bad;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            s_rec[threadIdx.x] += s_rec[threadIdx.x + o];
-            s_drop[threadIdx.x] += s_drop[threadIdx.x + o];
-            s_bad[threadIdx.x] = s_bad[threadIdx.x] > s_bad[threadIdx.x + o] ? s_bad[threadIdx.x] : s_bad[threadIdx.x + o];
-        }
-        __syncthreads();
+    // the wavefront's sums (64-bit shuffles)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rec += __shfl_down(rec, o);
+        drop += __shfl_down(drop, o);
+        const unsigned long long ob = __shfl_down(bad, o);
+        bad = ob > bad ? ob : bad;
     }
     if (threadIdx.x == 0) {
-        if (s_bad[0])
-            atomicMax(acc, s_bad[0]);
-        atomicAdd(acc + 1, s_rec[0]);
-        atomicAdd(acc + 2, s_drop[0]);
+        if (bad)
+            atomicMax(acc, bad);
+        atomicAdd(acc + 1, rec);
+        atomicAdd(acc + 2, drop);
         __threadfence(); // this workgroup's sums are visible device-wide before its ticket is
-        s_last = atomicAdd(acc + 4, 1ull) + 1 == (unsigned long long)gridDim.x;
-        if (s_last) { // every other workgroup's atomics came before its ticket: read them back with atomics too
+        const bool last = atomicAdd(acc + 4, 1ull) + 1 == (unsigned long long)gridDim.x;
+        if (last) { // every other workgroup's atomics came before its ticket: read them back with atomics too
             for (int i = 0; i < 4; ++i)
                 host_out[i] = atomicExch(acc + i, 0ull);
             atomicExch(acc + 4, 0ull);
@@ -757,9 +755,9 @@ hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_
     if (n_frames == 0)
         return hipSuccess;
     // a handful of small workgroups: the call runs beside a fused launch that leaves FRAME_RESERVE_BLOCKS workgroup slots free
-    // (a slot is four wavefronts of 128 registers, or more: four of these 256-thread, < 32-register workgroups fit one)
-    const unsigned blocks = (unsigned)std::min<size_t>(4 * FRAME_RESERVE_BLOCKS, (n_frames + 255) / 256);
-    hipLaunchKernelGGL(adcdac_verdict_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, payload_ok, check,
+    // (a slot is two or more wavefronts of 128 registers: several of these one-wavefront, < 32-register workgroups fit one)
+    const unsigned blocks = (unsigned)std::min<size_t>(16 * FRAME_RESERVE_BLOCKS, (n_frames + VERDICT_THREADS - 1) / VERDICT_THREADS);
+    hipLaunchKernelGGL(adcdac_verdict_kernel, dim3(blocks), dim3(VERDICT_THREADS), 0, s, frames, frame_size, n_frames, batches, payload_ok, check,
                        n_loss, acc, host_out);
     return hipGetLastError();
 }
