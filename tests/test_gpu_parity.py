@@ -1259,3 +1259,38 @@ def test_n16384_deep_single_pass_vs_oracle(pkg, ora, gpu_required):
     assert counts[:5] == [16383, 2046, 254, 30, 2] == [s for _, s, _ in pkg.plan_counts(n, total)][:5]
     print(f"N=16384 x 2^27 samples vs the f64 oracle: stages {counts}, worst relative error {w:.3g}")
     g.close()
+
+
+@pytest.mark.parametrize("n,bad", [(1024, float("nan")), (1024, float("inf")), (4096, float("nan")), (16384, float("-inf")), (64, float("nan"))])
+def test_non_finite_samples_propagate_like_the_reference(pkg, ora, gpu_required, n, bad):
+    """A NaN / infinity in the stream is not an error in the reference: it goes through window, FFT and the running sums
+    (src/psd.rs:211-233) and through the half-band filters into the next stage (:246-253).  Where it lands is decided by
+    the stream bookkeeping alone, so the pattern of non-finite bins must equal the oracle's stage by stage (an infinity
+    becomes NaN in the FFT: inf - inf); the finite bins keep the tolerance.  Nothing hangs or faults, and the handle works
+    on after a reset by drop (src/bin/psd.rs:190)."""
+    import torch
+    total = 300 * n
+    x = make_signal(pkg, total, seed=900 + n, tone=0.1)
+    x[7 * n + 5] = np.float32(bad)  # one sample, early: stage 0 loses two segments to it, the deeper stages what the filters spread
+    g = pkg.PsdCascadeBank(n)
+    d = torch.from_numpy(x).cuda()
+    g.process_device(0, d.data_ptr(), total)
+    ref = ora.PsdCascade(n, "f64")
+    ref.process(x)
+    assert g.num_stages(0) == ref.num_stages
+    saw_bad = False
+    for k in range(ref.num_stages):
+        assert g.stage_info(0, k) == ref.stage_info(k)
+        sg, sr = np.asarray(g.stage_spectrum(0, k), dtype=np.float64), np.asarray(ref.stage_spectrum(k), dtype=np.float64)
+        assert np.array_equal(np.isfinite(sg), np.isfinite(sr)), f"N={n} stage {k}: non-finite pattern differs"
+        saw_bad = saw_bad or not np.all(np.isfinite(sr))
+        fin = np.isfinite(sr)
+        if np.any(fin) and ref.stage_info(k)["count"]:
+            assert_psd_close(sg[fin], sr[fin], f"N={n} stage {k} with a non-finite sample upstream")
+    assert saw_bad  # (the sums never recover: every bin of stage 0 is non-finite from that segment on)
+    g.close()
+    h = pkg.PsdCascadeBank(n)  # a fresh cascade (the binaries reset by dropping it) is clean
+    y = make_signal(pkg, 40 * n, seed=5)
+    h.process(0, y)
+    check_against_oracle(pkg, ora, h, [y], n, what=f"N={n} after a reset")
+    h.close()
