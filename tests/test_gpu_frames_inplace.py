@@ -138,3 +138,36 @@ def test_config3_frames_in_place_full_size(pkg, ora, gpu_required):
         print(f"config 3 (frames in HBM, read in place) {pkg.ADCDAC_TRACES[c]}: worst relative error {w:.3g}")
     g.close()
     g2.close()
+
+
+@pytest.mark.timeout(900)
+def test_one_call_longer_than_a_frame_span(pkg, ora, gpu_required):
+    """One call of more than 2^26 samples per trace: the in-place path cuts it into spans of at most FSPAN_MAX_SAMPLES (the
+    kernels' cell arithmetic is exact below 2^24 cells), whose seams are stream seams like any other.  ADC0 and DAC1
+    against the f64 oracle (pure 1e-5 on stages with four averages); every trace's counters against the closed form."""
+    import torch
+    n, batches = 4096, 22
+    per_frame = 8 * batches
+    nframes = (1 << 26) // per_frame + 20011  # 401 312 frames, 70.6 M samples per trace: two spans
+    per = nframes * per_frame
+    assert per > (1 << 26)
+    lsb = np.float32(4.096 * 2.5 / 32768.0)
+    words = np.stack([np.clip(np.round(pkg.noise_host(per, 0x1234567 + c).astype(np.float64) * 4096), -32768, 32767)
+                      .astype(np.int16) for c in range(4)])
+    wire = words.copy()
+    wire[2:] = (wire[2:].view(np.uint16) ^ np.uint16(0x8000)).view(np.int16)
+    data, fs = pkg.make_adcdac_frames(wire, batches, seq0=17)
+    d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    del data, wire
+    g = pkg.PsdCascadeBank(n, 4)
+    assert g.process_adcdac_frames_device(d.data_ptr(), fs, nframes) == nframes
+    g.sync()
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    infos = [[g.stage_info(c, k) for k in range(g.num_stages(c))] for c in range(4)]
+    assert all(i == infos[0] for i in infos)  # same stream length -> same counters on every trace
+    for c in (0, 3):
+        xc = words[c].astype(np.float32) * lsb
+        w = check_against_oracle(pkg, ora, g, [xc], n, channel=c, what=f"70.6 M-sample call, {pkg.ADCDAC_TRACES[c]}",
+                                 pure_min_count=4, justify=False)
+        print(f"one call of 2^26 + samples per trace, {pkg.ADCDAC_TRACES[c]}: worst relative error {w:.3g}")
+    g.close()
