@@ -31,7 +31,9 @@ def make_frames(pkg, ora, nframes, batches, seed, seq0=0, scale=3000.0):
 @pytest.mark.parametrize("n,batches,detrend", [(2048, 22, "none"), (4096, 22, "none"), (4096, 7, "mean"), (4096, 1, "span"),
                                                (8192, 31, "midpoint"), (16384, 22, "none"), (4096, 13, "none"),
                                                (256, 22, "none"), (512, 22, "mean"), (512, 3, "midpoint"), (1024, 22, "none"),
-                                               (1024, 9, "span")])
+                                               (1024, 9, "span"),
+                                               # sizes without a fused kernel: every call is decoded into the stage-0 streams (adcdac_kernel)
+                                               (64, 5, "mean"), (128, 22, "none"), (1200, 22, "none")])
 def test_frames_in_place(pkg, ora, gpu_required, n, batches, detrend):
     """Uneven calls (long enough to be read in place, and short ones that are decoded), a read-out in between, the u32
     sequence wrapping, a gap: every stage of the four cascades against the oracle on the decoded traces."""
@@ -170,4 +172,22 @@ def test_one_call_longer_than_a_frame_span(pkg, ora, gpu_required):
         w = check_against_oracle(pkg, ora, g, [xc], n, channel=c, what=f"70.6 M-sample call, {pkg.ADCDAC_TRACES[c]}",
                                  pure_min_count=4, justify=False)
         print(f"one call of 2^26 + samples per trace, {pkg.ADCDAC_TRACES[c]}: worst relative error {w:.3g}")
+    g.close()
+
+
+def test_frames_device_rectangular_window(pkg, ora, gpu_required):
+    """Window::rectangular() (overlap 0: the generic two-pass kernels): device-resident frames are decoded into the stage-0
+    streams instead of being read in place -- same traces, same Loss, same spectra."""
+    import torch
+    n, batches = 1024, 22
+    nframes = (120 * n) // (8 * batches) + 9
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=31)
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4, window=pkg.Window.RECTANGULAR)
+    half = nframes // 2
+    assert g.process_adcdac_frames_device(d.data_ptr(), fs, half) == half
+    assert g.process_adcdac_frames_device(d.data_ptr() + half * fs, fs, nframes - half) == nframes - half
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, channel=c, window="rect", what=f"rectangular window, frames in HBM, trace {c}")
     g.close()
