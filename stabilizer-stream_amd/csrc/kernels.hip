@@ -44,14 +44,20 @@ __device__ __forceinline__ float ewma_amp(const SegJob &job, int step)
     return (float)exp2(0.5 * (double)na * job.log2_gamma); // log2_gamma = -inf -> 0
 }
 
-template <int N, int P>
+// POWER_ONLY: only |X|^2 of the outputs is consumed, so the inputs of the last pass may be read rotated within their
+// butterflies (pass_load: the outputs pick up unit phases) -- fewer LDS bank conflicts in the unpadded frame at the sizes
+// listed (tests/host/fft_emul.cpp, FFT_EMUL_ROT_ALL=1: last-pass read cycles 128 -> 64 at N = 256, 160 -> 64 at 1024,
+// 768 -> 384 at 2048, 2304 -> 768 at 4096, 6656 -> 5120 at 16384; 512 and 8192 do not change).  The first transform of the
+// chirp-z kernel needs the outputs themselves and must not rotate: it did at M = 1024 (sizes 256 < N <= 512 that are not
+// powers of two read wrong spectra until round 3's last day; tests/test_gpu_any_n.py now covers every transform length).
+template <int N, int P, bool POWER_ONLY>
 __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__restrict__ tw)
 {
     using PI = PassInfo<N, P>;
     if constexpr (P > 0) {
         int rot = 0;
-        if constexpr (N == 1024 && PI::LAST)
-            rot = (t >> 3) & (PI::R - 1); // bank-conflict-free last-pass reads
+        if constexpr (POWER_ONLY && PI::LAST && (N == 256 || N == 1024 || N == 2048 || N == 4096 || N == 16384))
+            rot = (t >> 3) & (PI::R - 1); // fewer bank conflicts in the last-pass reads
         pass_load<N, P>(t, v, frame, rot);
     }
     pass_compute<N, P>(t, v, tw);
@@ -60,7 +66,7 @@ __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__
             __syncthreads(); // previous iteration's last-pass reads are done
         pass_store<N, P>(t, v, frame);
         __syncthreads();
-        fft_passes<N, P + 1>(t, v, frame, tw);
+        fft_passes<N, P + 1, POWER_ONLY>(t, v, frame, tw);
     }
 }
 
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                 v[s].im = b;
             }
 
-        fft_passes<N, 0>(t, v, frame, tw);
+        fft_passes<N, 0, true>(t, v, frame, tw);
 
 #pragma unroll
         for (int s = 0; s < E; ++s)
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
                 v[s] = z;
             }
 
-        fft_passes<M, 0>(t, v, frame, twm); // Y = FFT_M(y): slot s holds bin freq_of_slot<M>(t, s)
+        fft_passes<M, 0, false>(t, v, frame, twm); // Y = FFT_M(y): slot s holds bin freq_of_slot<M>(t, s) (the VALUES are used: no rotation)
         __syncthreads();                    // everybody's last-pass reads of the frame are done
 #pragma unroll
         for (int s = 0; s < E; ++s) { // conj(Y B), back in natural order for the second transform
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
 #pragma unroll
             for (int m = 0; m < P0::R; ++m)
                 v[i * P0::R + m] = frame[lds_swz<M>(P0::elem(t, i, m))];
-        fft_passes<M, 0>(t, v, frame, twm); // M conj(convolution): slot s holds output index freq_of_slot<M>(t, s)
+        fft_passes<M, 0, true>(t, v, frame, twm); // M conj(convolution): slot s holds output index freq_of_slot<M>(t, s); only |.|^2 is used
 #pragma unroll
         for (int s = 0; s < E; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));

@@ -453,6 +453,14 @@ int main()
     bad |= check<512>(false);
     bad |= check<1024>(false);
     bad |= check<1024>(true);
+    if (getenv("FFT_EMUL_ROT_ALL")) {
+        bad |= check<256>(true);
+        bad |= check<512>(true);
+        bad |= check<2048>(true);
+        bad |= check<4096>(true);
+        bad |= check<8192>(true);
+        bad |= check<16384>(true);
+    }
     bad |= check<2048>(false);
     bad |= check<4096>(false);
     bad |= check<8192>(false);

@@ -11,7 +11,9 @@ from test_gpu_parity import check_against_oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,detrend", [(48, "none"), (80, "mean"), (112, "midpoint"), (240, "span"), (1200, "none"), (1200, "mean"),
+# (one size at least per chirp-z transform length M = 128 ... 16384: 48 | 80, 112 | 240 | 272, 400, 496 | 1008 | 1200 | 3056 | 6000, 8176)
+@pytest.mark.parametrize("n,detrend", [(48, "none"), (80, "mean"), (112, "midpoint"), (240, "span"), (272, "none"), (400, "mean"),
+                                       (496, "none"), (1008, "none"), (1200, "none"), (1200, "mean"),
                                        (3056, "none"), (6000, "none"), (8176, "none")])
 def test_cascade_any_n_hann(pkg, ora, gpu_required, n, detrend):
     """PsdCascade::<N>::default() (Hann, overlap N/2: N a multiple of 16) for sizes with factors 3, 5, 7, 191 ...: host-fed in odd
