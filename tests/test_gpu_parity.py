@@ -962,7 +962,9 @@ def test_single_stage_reference_test_shape(pkg, ora, gpu_required):
 
 
 @pytest.mark.parametrize("n,window,detrend", [(64, "hann", "none"), (256, "hann", "mean"), (1024, "hann", "none"),
-                                              (1024, "hann", "span"), (4096, "hann", "midpoint"), (128, "rect", "none")])
+                                              (1024, "hann", "span"), (4096, "hann", "midpoint"), (128, "rect", "none"),
+                                              (512, "hann", "none"), (2048, "hann", "mean"), (8192, "hann", "none"),
+                                              (16384, "hann", "mean"), (400, "hann", "none")])
 def test_single_stage_chunked(pkg, ora, gpu_required, n, window, detrend):
     """PsdStage::process call by call with odd chunk sizes (empty, shorter than a segment, many segments): every
     call returns exactly the items the reference's loop emits for the segments that call completes, and the
