@@ -161,6 +161,18 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         const_cast<uint8_t *>(fsp.frames), 0, fr ? (int)min(fsp.bytes, 0x7FFFFFFFull) : 0, 0x00020000);
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tp;
     unsigned sp = job.s_off + (unsigned)p0 * N + 4u * tp;
+    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words in .x / .y
+    auto piece = [&](const float4 *c, unsigned s, int k) -> float4 {
+        if constexpr (FRAMES) {
+            if (fr) {
+                const unsigned si = s + 4u * (unsigned)k;
+                const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0); // (a GCC-style vector of two u32: index it)
+                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+            }
+        }
+        return c[k];
+    };
     // raw wire words -> volts, in place (a no-op for f32 jobs)
     auto volts = [&](float4 &g) {
         if constexpr (FRAMES) {
@@ -174,44 +186,6 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             }
         }
     };
-    // The pieces a lane loads in one go sit TEAM float4s = N/32 cells apart: cell c0 + (N/32) j = frame f0 + dq_j (+1), batch
-    // b0 + dr_j (- batches) with (dq_j, dr_j) = divmod((N/32) j, batches) the same for every lane, and a wrap of the batch index
-    // into the next frame costs exactly that frame's 8 header bytes -- ONE division per group of loads (bigfused3_impl.h).
-    unsigned fdr[6], fdc[6];
-    if constexpr (FRAMES) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const unsigned d = (unsigned)((N / 32) * j);
-            const unsigned dq = fsp.batches == 1 ? d : __umulhi(d, fsp.magic);
-            fdr[j] = d - dq * fsp.batches;
-            fdc[j] = dq * fsp.frame_size + 64u * fdr[j];
-        }
-    }
-    // CNT consecutive pieces k = K0 TEAM, (K0 + 1) TEAM, ... of a lane (float4 units from c / 4 k samples from s)
-    auto pieces = [&](const float4 *c, unsigned s, int k0, float4 **out, int cnt) {
-        if constexpr (FRAMES) {
-            if (fr) {
-                const unsigned si = s + 4u * (unsigned)(k0 * TEAM);
-                const unsigned c0 = si >> 3;
-                const unsigned f0 = fsp.batches == 1 ? c0 : __umulhi(c0, fsp.magic);
-                const unsigned b0 = c0 - __umul24(f0, fsp.batches);
-                const unsigned off0 = __umul24(f0, fsp.frame_size) + 8u + b0 * 64u + ch_off + (si & 4u) * 2u;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    if (j < cnt) {
-                        const unsigned off = off0 + fdc[j] + ((b0 + fdr[j] >= fsp.batches) ? 8u : 0u);
-                        const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-                        *out[j] = make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
-                    }
-                }
-                return;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (j < cnt)
-                *out[j] = c[(k0 + j) * TEAM];
-    };
     const float4 *safe = cp; // look-ahead target once nothing is left to look ahead to
     unsigned safe_s = sp;
     // register groups of a lane: two float4 each (see pair_step)
@@ -220,8 +194,12 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     for (int v = 0; v < VT; ++v) {
         const float4 *c = cp + THREADS * v;
         const unsigned s = sp + 4u * THREADS * v;
-        float4 *six[6] = {&ga[v][0], &ga[v][1], &gb[v][0], &gb[v][1], &gc[v][0], &gc[v][1]}; // (N / 4 float4s = 4 TEAM)
-        pieces(c, s, 0, six, 6);
+        ga[v][0] = piece(c, s, 0);
+        ga[v][1] = piece(c, s, TEAM);
+        gb[v][0] = piece(c, s, 2 * TEAM);
+        gb[v][1] = piece(c, s, 3 * TEAM);
+        gc[v][0] = piece(c, s, N / 4);
+        gc[v][1] = piece(c, s, N / 4 + TEAM);
     }
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
@@ -629,8 +607,10 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             for (int v = 0; v < VT; ++v) {
                 const float4 *c = src + THREADS * v;
                 const unsigned s = ssrc + 4u * THREADS * v;
-                float4 *four[6] = {&up[v][0], &up[v][1], &lo[v][0], &lo[v][1], nullptr, nullptr};
-                pieces(c, s, 2, four, 4);
+                up[v][0] = piece(c, s, 2 * TEAM);
+                up[v][1] = piece(c, s, 3 * TEAM);
+                lo[v][0] = piece(c, s, N / 4);
+                lo[v][1] = piece(c, s, N / 4 + TEAM);
             }
         }
         PSDK_FFT_BARRIER();

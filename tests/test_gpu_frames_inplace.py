@@ -191,3 +191,26 @@ def test_frames_device_rectangular_window(pkg, ora, gpu_required):
     for c in range(4):
         check_against_oracle(pkg, ora, g, [traces[c]], n, channel=c, window="rect", what=f"rectangular window, frames in HBM, trace {c}")
     g.close()
+
+
+@pytest.mark.parametrize("n,detrend,avg", [(512, "none", (7, 900)), (1024, "mean", (40, 3000)), (2048, "span", (3, 50)),
+                                           (4096, "none", (25, 2000)), (8192, "midpoint", (5, 100)), (16384, "mean", (2, 30))])
+def test_frames_in_place_with_finite_averaging(pkg, ora, gpu_required, n, detrend, avg):
+    """AvgOpts { limit, count } (src/psd.rs:360-376, per-stage rule :447-450) on frames read in place: the EWMA + FRAMES variants of
+    the team, three-pass and four-pass kernels, against the oracle on the decoded traces."""
+    import torch
+    batches = 22
+    nframes = (220 * n) // (8 * batches) + 5
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=3 * n + avg[0])
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    g = pkg.PsdCascadeBank(n, 4)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    a = pkg.AvgOpts(*avg)
+    g.set_avg(a)
+    third = nframes // 3
+    for lo, hi in ((0, third), (third, 2 * third + 1), (2 * third + 1, nframes)):
+        assert g.process_adcdac_frames_device(d.data_ptr() + lo * fs, fs, hi - lo) == hi - lo
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, detrend=detrend, avg=a, channel=c,
+                             what=f"frames in place N={n} {detrend} avg={avg} trace {c}")
+    g.close()

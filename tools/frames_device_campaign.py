@@ -22,11 +22,14 @@ for seed in range(first, first + count):
     per_frame = batches * 8
     nframes = int(rng.integers(30 * n, 260 * n)) // per_frame
     detrend = ["none", "midpoint", "span", "mean"][int(rng.integers(0, 4))]
+    avg = None if rng.random() < 0.55 else pkg.AvgOpts(int(rng.integers(1, 60)), int(rng.integers(1, 3000)))  # (the EWMA + FRAMES kernel variants)
     try:
         buf, fs, traces = F.make_frames(pkg, ora, nframes, batches, seed=seed, seq0=int(rng.integers(0, 2**32)))
         d = torch.from_numpy(buf.reshape(-1)).cuda()
         g = pkg.PsdCascadeBank(n, 4)
         g.set_detrend(pkg.Detrend[detrend.upper()])
+        if avg is not None:
+            g.set_avg(avg)
         co = int(rng.integers(1, 9))
         g.configure(coalesce=-co if rng.random() < 0.5 else co)
         pos = 0
@@ -39,9 +42,9 @@ for seed in range(first, first + count):
                 g.num_stages(int(rng.integers(0, 4)))
         assert g.loss() == {"received": nframes * batches, "dropped": 0}, g.loss()
         for c in range(4):
-            T.check_against_oracle(pkg, ora, g, [traces[c]], n, detrend=detrend, channel=c, what=f"seed {seed} trace {c}")
+            T.check_against_oracle(pkg, ora, g, [traces[c]], n, detrend=detrend, avg=avg, channel=c, what=f"seed {seed} trace {c}")
         g.close()
-        print(f"seed {seed} n={n} batches={batches} frames={nframes} {detrend} coalesce {co} ok ({time.time() - t0:.0f}s)", flush=True)
+        print(f"seed {seed} n={n} batches={batches} frames={nframes} {detrend} avg={avg} coalesce {co} ok ({time.time() - t0:.0f}s)", flush=True)
     except Exception:
         bad += 1
         print(f"seed {seed} n={n} batches={batches} frames={nframes} FAILED", flush=True)
