@@ -456,13 +456,14 @@ template <int N>
 hipError_t launch_bigfused3_n(const FusedBatch &b, const float *win, const cf *tw0g, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     const dim3 grid(b.nblocks), block(Big3Geo<N>::THREADS);
+    const bool ew_ = b.any_ewma || (dbg_variant() & 1), frm_ = b.any_frames || (dbg_variant() & 2);
 #define PSDK_BIG3_CASE(D)                                                                         \
     case D:                                                                                       \
-        if (b.any_frames && b.any_ewma)                                                           \
+        if (frm_ && ew_)                                                                          \
             hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
-        else if (b.any_frames)                                                                    \
+        else if (frm_)                                                                            \
             hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
-        else if (b.any_ewma)                                                                      \
+        else if (ew_)                                                                             \
             hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
         else                                                                                      \
             hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \

@@ -706,13 +706,14 @@ static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStrea
     static_assert(FusedGeo<N>::LDS_BYTES * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES) <= 163840,
                   "the workgroups of a CU (two of eight waves by default) share its 160 KiB of LDS");
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
+    const bool ew_ = b.any_ewma || (dbg_variant() & 1), frm_ = b.any_frames || (dbg_variant() & 2);
 #define PSDK_FUSED_CASE(D)                                                                \
     case D:                                                                               \
-        if (b.any_frames && b.any_ewma)                                                   \
+        if (frm_ && ew_)                                                                  \
             hipExtLaunchKernelGGL((fused_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
-        else if (b.any_frames)                                                            \
+        else if (frm_)                                                                    \
             hipExtLaunchKernelGGL((fused_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win); \
-        else if (b.any_ewma)                                                              \
+        else if (ew_)                                                                     \
             hipExtLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
         else                                                                              \
             hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win); \

@@ -2,6 +2,7 @@
 // the gfx950 kernels (kernels.hip).  Job descriptors travel by value in the
 // kernel argument segment (no descriptor copies, graph-capturable).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <vector>
@@ -202,6 +203,18 @@ hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_fram
 // max ~(index << 2 | code) over the bad frames (0: none), [1] batches received, [2] sequence gaps, [3] first seq | next seq
 // << 32.  acc: 5 device words, zero before the first call (the kernel leaves them zero).
 constexpr int FRAME_RESERVE_BLOCKS = 8; // workgroup slots a frame round leaves free for it (it runs beside the fused launch)
+// $PSDC_DBG_VARIANT (test aid, read once): bit 0 runs every fused launch on the EWMA kernel variants (weights of 1 for plain
+// sums), bit 1 on the FRAMES variants (no framed job: the f32 path of those kernels) -- the whole suite then exercises the
+// variants that only finite averaging / AdcDac frames reach otherwise.
+inline int dbg_variant()
+{
+    static const int v = [] {
+        const char *e = getenv("PSDC_DBG_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok, int check,
                                  size_t n_loss, unsigned long long *acc, unsigned long long *host_out, hipStream_t s);
 

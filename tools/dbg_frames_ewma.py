@@ -8,7 +8,8 @@ n, batches = 8192, 22
 nframes = (220 * n) // (8 * batches) + 5
 buf, fs, traces = F.make_frames(pkg, ora, nframes, batches, seed=1)
 d = torch.from_numpy(buf.reshape(-1)).cuda()
-for avg in (None, (5, 100), (1000000, 1000000)):
+import os
+for avg in ([tuple(int(v) for v in a.split(',')) for a in os.environ['DBG_AVGS'].split(';')] if os.environ.get('DBG_AVGS') else (None, (5, 100), (1000000, 1000000))):
     for calls in (1, 3):
         g = pkg.PsdCascadeBank(n, 4)
         if avg: g.set_avg(pkg.AvgOpts(*avg))
@@ -25,6 +26,8 @@ for avg in (None, (5, 100), (1000000, 1000000)):
         rel = np.abs(sg - sr) / np.max(sr)
         print("avg", avg, "calls", calls, "count", g.stage_info(0,0)["count"], ref.stage_info(0)["count"], "max rel err", rel.max(), "bins bad", int((rel > 1e-4).sum()))
         g.close()
+import sys as _s
+if os.environ.get("DBG_AVGS"): _s.exit(0)
 print("---- detail")
 for n in (8192, 4096):
     nframes = (220 * n) // (8 * batches) + 5
