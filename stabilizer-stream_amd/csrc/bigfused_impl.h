@@ -86,6 +86,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 {
     // stage A of the decimator from registers + scalar-loaded boundary samples (see pair_step); f32 streams only
     constexpr bool REGA = PSDK_REGA != 0 && !FRAMES && BigGeo<N>::VT == 1;
+#ifndef PSDK_HOIST_LOOKAHEAD
+#define PSDK_HOIST_LOOKAHEAD 1
+#endif
     using G = BigGeo<N, REGA>;
     using T = BlockFft<N>;
     constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
@@ -607,10 +610,35 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             for (int v = 0; v < VT; ++v) {
                 const float4 *c = src + THREADS * v;
                 const unsigned s = ssrc + 4u * THREADS * v;
+#if PSDK_HOIST_LOOKAHEAD
+                // (the frame / f32 decision once for the four loads: with it inside piece(), every load sat in a branch of its own whose
+                // result reached its register group through a copy at the join, behind an s_waitcnt vmcnt(0) -- the look-ahead loads
+                // went out one at a time; N = 8192 frames +8 %, 16384 +5 %.  The SIX loads at the start of a run stay as they are:
+                // hoisted the same way they read components .x / .y of the first group wrong in the EWMA x FRAMES variant alone --
+                // DESIGN.md section 4)
+                if (FRAMES && fr) {
+                    auto fp = [&](int k) {
+                        const unsigned si = s + 4u * (unsigned)k;
+                        const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                        const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                        return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+                    };
+                    up[v][0] = fp(2 * TEAM);
+                    up[v][1] = fp(3 * TEAM);
+                    lo[v][0] = fp(N / 4);
+                    lo[v][1] = fp(N / 4 + TEAM);
+                } else {
+                    up[v][0] = c[2 * TEAM];
+                    up[v][1] = c[3 * TEAM];
+                    lo[v][0] = c[N / 4];
+                    lo[v][1] = c[N / 4 + TEAM];
+                }
+#else
                 up[v][0] = piece(c, s, 2 * TEAM);
                 up[v][1] = piece(c, s, 3 * TEAM);
                 lo[v][0] = piece(c, s, N / 4);
                 lo[v][1] = piece(c, s, N / 4 + TEAM);
+#endif
             }
         }
         PSDK_FFT_BARRIER();

@@ -969,7 +969,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 np = 0;
             if (np) {
                 FusedJob fj{};
-                fj.src = fsrc;
+                // (a frame job never reads through src, but the kernels form per-lane pointers from it before they know: keep that
+                // arithmetic off a null pointer -- any valid device address will do)
+                fj.src = framed ? h->d_win : fsrc;
                 fj.fspan = sp.fpool;
                 fj.fch = sp.fch;
                 fj.s_off = framed ? (unsigned)fofs : 0u;
