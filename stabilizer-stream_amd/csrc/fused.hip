@@ -28,6 +28,10 @@
 #include "frames.h"
 #include "fused_common.h"
 
+#ifndef PSDK_HOIST_LOOKAHEAD
+#define PSDK_HOIST_LOOKAHEAD 1
+#endif
+
 namespace psdk {
 
 // -DPSDK_STAMPS (tools/stamps): the first wavefront of workgroup 0 sums the s_memtime ticks it
@@ -500,10 +504,32 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             safe = src;
             safe_s = ssrc;
             if constexpr (!(PSDK_ABL & 64)) {
+#if PSDK_HOIST_LOOKAHEAD
+            // (the frame / f32 decision once for the four loads, as in bigfused_impl.h: a branch per load put each load behind
+            // an s_waitcnt vmcnt(0) at its join)
+            if (FRAMES && fr) {
+                auto fp = [&](int k) {
+                    const unsigned si = ssrc + 4u * (unsigned)k;
+                    const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                    return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+                };
+                up[0] = fp(2 * TEAM);
+                up[1] = fp(3 * TEAM);
+                lo[0] = fp(N / 4);
+                lo[1] = fp(N / 4 + TEAM);
+            } else {
+                up[0] = src[2 * TEAM];
+                up[1] = src[3 * TEAM];
+                lo[0] = src[N / 4];
+                lo[1] = src[N / 4 + TEAM];
+            }
+#else
             up[0] = piece(src, ssrc, 2 * TEAM);
             up[1] = piece(src, ssrc, 3 * TEAM);
             lo[0] = piece(src, ssrc, N / 4);
             lo[1] = piece(src, ssrc, N / 4 + TEAM);
+#endif
             }
         }
         PSDK_STAMP(5);

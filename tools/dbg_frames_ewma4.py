@@ -4,7 +4,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import torch
 import __graft_entry__ as e
 pkg, ora = e.load_package(), e.load_oracle()
-n, batches = 8192, 22
+n, batches = int(os.environ.get("DBG_N", "8192")), 22
 per_frame = 8 * batches
 nframes = (40 * n) // per_frame + 5
 per = nframes * per_frame
