@@ -7,9 +7,16 @@ pkg = e.load_package()
 x = pkg.noise_host(1 << 20, 5)
 d = torch.from_numpy(x).cuda()
 frames, fs = pkg.make_adcdac_frames((np.random.default_rng(1).standard_normal((4, 22 * 8 * 200)) * 3000).astype(np.int16), 22)
+dframes = torch.from_numpy(np.frombuffer(frames, dtype=np.uint8).copy()).cuda()  # the same frames resident in HBM (read in place)
+nfr = len(frames) // fs
+def hamming(n):
+    i = np.arange(n, dtype=np.float64)
+    w = (0.54 - 0.46 * np.cos(2 * np.pi * i / n)).astype(np.float32)
+    m1, m2 = float(np.mean(w.astype(np.float64))), float(np.mean(w.astype(np.float64) ** 2))
+    return pkg.WindowTable(w, np.float32(m1 * m1).item(), np.float32(m2 / (m1 * m1)).item(), n // 2)
 def cycle(i):
-    n = (256, 1024, 4096, 16384)[i % 4]
-    g = pkg.PsdCascadeBank(n, 4)
+    n = (256, 1024, 4096, 16384, 400)[i % 5]
+    g = pkg.PsdCascadeBank(n, 4, window=hamming(n) if i % 7 == 3 else pkg.Window.HANN)
     g.set_detrend(pkg.Detrend(i % 4))
     if i % 3 == 0:
         g.set_avg(pkg.AvgOpts(50, 5000))
@@ -17,6 +24,10 @@ def cycle(i):
     g.process_device(1, d.data_ptr(), x.size)
     g.process_device(1, d.data_ptr(), x.size)
     g.process_adcdac_frames(frames, fs)
+    g.process_adcdac_frames_device(dframes.data_ptr(), fs, nfr)
+    g.process_adcdac_frames_device(dframes.data_ptr(), fs, nfr)
+    rec = g.pack_readout()
+    pkg.unpack_stitch(rec, 2)
     c = g.clone()
     p, br = g.psd(0)
     c.psd(1)
