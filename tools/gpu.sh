@@ -4,6 +4,7 @@
 # Everything lands under gpurun_out/<mode>/.  A step killed by its timeout ends the call (no further GPU step).
 #
 #   tests [pytest args]     pytest -m gpu
+#   allvariants [args]      pytest -m gpu under PSDC_DBG_VARIANT = 0, 1, 2, 3 (every fused launch on the EWMA / FRAMES kernel variants)
 #   smoke                   __graft_entry__.smoke()
 #   bench [bench args]      one bench.py line, condensed
 #   lines "<args>" ...      one condensed bench line per quoted argument string
@@ -44,6 +45,13 @@ case $mode in
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -q -x --timeout 900 "$@" > "$out/pytest.log" 2>&1; rc=$?
   echo "pytest rc=$rc"; tail -8 "$out/pytest.log"; exit $rc ;;
+allvariants)
+  # the whole GPU suite on each of the four kernel variants (PSDC_DBG_VARIANT: bit 0 EWMA, bit 1 FRAMES kernels for every fused launch)
+  for v in 0 1 2 3; do
+    PSDC_DBG_VARIANT=$v timeout -k 10 400 python -m pytest tests -m gpu -q -x --timeout 900 "$@" > "$out/pytest_v$v.log" 2>&1; rc=$?
+    echo "PSDC_DBG_VARIANT=$v rc=$rc: $(tail -1 "$out/pytest_v$v.log")"
+    if [ $rc -ne 0 ]; then tail -8 "$out/pytest_v$v.log"; exit $rc; fi
+  done ;;
 smoke)
   timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
 bench)
