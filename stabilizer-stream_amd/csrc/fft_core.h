@@ -260,8 +260,11 @@ struct PassInfo {
 template <int N>
 PSDK_HD int lds_swz(int idx)
 {
-    if constexpr (N == 1024)
-        return idx ^ ((idx >> 4) & 0x1C);
+#ifndef PSDK_SWZ_MAX
+#define PSDK_SWZ_MAX 4096
+#endif
+    if constexpr (N >= 256 && N <= PSDK_SWZ_MAX)
+        return idx ^ ((idx >> 4) & 0x1F); // (256 ... 4096 since round 3: the unswizzled frame read at up to 9x the ideal LDS cycles)
     else
         return idx;
 }

@@ -45,9 +45,9 @@ __device__ __forceinline__ float ewma_amp(const SegJob &job, int step)
 }
 
 // POWER_ONLY: only |X|^2 of the outputs is consumed, so the inputs of the last pass may be read rotated within their
-// butterflies (pass_load: the outputs pick up unit phases) -- fewer LDS bank conflicts in the unpadded frame at the sizes
-// listed (tests/host/fft_emul.cpp, FFT_EMUL_ROT_ALL=1: last-pass read cycles 128 -> 64 at N = 256, 160 -> 64 at 1024,
-// 768 -> 384 at 2048, 2304 -> 768 at 4096, 6656 -> 5120 at 16384; 512 and 8192 do not change).  The first transform of the
+// butterflies (pass_load: the outputs pick up unit phases) -- fewer LDS bank conflicts at the sizes listed, on top of the
+// frame's XOR swizzle (fft_core.h lds_swz; tests/host/fft_emul.cpp, FFT_EMUL_ROT_ALL=1: read cycles 96 -> 64 at N = 1024,
+// 192 -> 176 at 2048, 2048 -> 1536 at 16384; the other sizes are at or near their ideal without it).  The first transform of the
 // chirp-z kernel needs the outputs themselves and must not rotate: it did at M = 1024 (sizes 256 < N <= 512 that are not
 // powers of two read wrong spectra until round 3's last day; tests/test_gpu_any_n.py now covers every transform length).
 template <int N, int P, bool POWER_ONLY>
@@ -56,7 +56,7 @@ __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__
     using PI = PassInfo<N, P>;
     if constexpr (P > 0) {
         int rot = 0;
-        if constexpr (POWER_ONLY && PI::LAST && (N == 256 || N == 1024 || N == 2048 || N == 4096 || N == 16384))
+        if constexpr (POWER_ONLY && PI::LAST && (N == 1024 || N == 2048 || N == 16384))
             rot = (t >> 3) & (PI::R - 1); // fewer bank conflicts in the last-pass reads
         pass_load<N, P>(t, v, frame, rot);
     }
