@@ -206,10 +206,20 @@ int psdc_record_consumed(psdc_handle *h, void *consumed_event);
 int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
                                size_t n_frames, size_t *n_ok);
 
-/* The same for frames that already sit in device memory (a capture buffer filled by a NIC / another kernel): headers
- * are validated and the Loss counters formed by two small kernels, the payloads de-interleaved straight into the
- * stage-0 streams.  The producer of d_frames must have completed; the frames are read before the call returns
- * only as far as the header scan -- keep them valid until psdc_sync() / a read-out / a psdc_record_consumed event. */
+/* The same for frames that already sit in device memory (a capture buffer filled by a NIC / another kernel).
+ * Headers: Header::parse and the AdcDac size checks of every frame plus the Loss sums are ONE small launch on a side stream
+ *   of the handle; the call waits for that launch alone, so `*n_ok` and the returned de::Error are final when it returns.
+ * Payloads: at every size with a fused kernel (powers of two 256 ... 16384, windows with overlap n/2) the four traces are
+ *   read IN PLACE, as wire words, by the stage-0 loads of the fused kernels -- the f32 traces never exist in memory --, under
+ *   the same rules as psdc_process_device: spans may be held back and share a round with later calls (PSDC_OPT_COALESCE), and
+ *   the seam / tail of a span is read by the FIRST launch of the next round, i.e. possibly after this call AND the next one
+ *   have returned.  Elsewhere (other sizes and windows, pieces shorter than 4 (n + 288) samples per trace) a decode kernel
+ *   writes the four traces into the stage-0 stream buffers.
+ * Lifetime: d_frames must stay valid and UNMODIFIED until psdc_sync(), any read-out, or an event from psdc_record_consumed
+ *   has completed.  Ordering: the handle works on its own non-blocking streams and there is no implicit null-stream order:
+ *   the producer of d_frames must have COMPLETED before the call (or use psdc_process_device_after's event for f32 spans).
+ * Alignment: any base address is accepted.  The in-place path needs d_frames to be a multiple of 8 bytes (frame_size =
+ *   8 + 64 batches keeps every later frame aligned); other bases take the byte-wise decode kernel -- same results, slower. */
 int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size,
                                       size_t n_frames, size_t *n_ok);
 
@@ -341,7 +351,11 @@ int psdc_stitch_window(uint32_t n, float power, float nenbw, size_t overlap, uin
  * the same on every shard with the same n and channel count, so one all-gather / gather of equal blocks over
  * ANY transport (RCCL ncclAllGather on device copies, MPI, a socket, or plain memcpy between the handles of one
  * process) collects them -- and the receiver stitches any channel of any record with psdc_unpack_stitch:
- * bit-identical to psdc_psd on the shard itself (raw accumulators travel, normalisation happens after). */
+ * bit-identical to psdc_psd on the shard itself (raw accumulators travel, normalisation happens after).
+ * A record is UNTRUSTED input to the psdc_unpack_* calls: every header field is held to the range the library can produce
+ * (2 <= n <= 16384, n_channels <= 4096, overlap < n, power and nenbw > 0, stage counts <= 16) and the length to what those
+ * fields imply, before anything is indexed; a record that fails is PSDC_ERR_ARG, never an out-of-bounds read.
+ * psdc_readout_bytes returns 0 for dimensions outside those ranges (no such record exists). */
 size_t psdc_readout_bytes(uint32_t n, uint32_t n_channels);
 /* flush + sync + copy: fills `buf` (cap >= psdc_readout_bytes(n, n_channels) of this handle) */
 int psdc_pack_readout(psdc_handle *h, void *buf, size_t cap, size_t *len);
@@ -351,6 +365,10 @@ int psdc_pack_readout(psdc_handle *h, void *buf, size_t cap, size_t *len);
 int psdc_pack_init(void *buf, size_t cap, uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_channels);
 int psdc_pack_channel(void *buf, size_t len, uint32_t channel, uint32_t n_stages, const uint64_t *counts64,
                       const uint32_t *avgs, const uint64_t *pendings, const float *spectra);
+/* A record copied into a larger one of `n_channels` channels, the added ones empty (no stages): a gather moves equal blocks,
+ * so with channels % world != 0 every shard pads its record to the largest shard's channel count.  Pure host; the counters stay
+ * the 64-bit ones.  cap >= psdc_readout_bytes(n, n_channels); out must not alias rec. */
+int psdc_pack_pad(const void *rec, size_t len, void *out, size_t cap, uint32_t n_channels);
 /* record header: FFT size, channels in the record, stages of `channel` (pure host) */
 int psdc_unpack_info(const void *buf, size_t len, uint32_t channel, uint32_t *n, uint32_t *n_channels,
                      uint32_t *n_stages);

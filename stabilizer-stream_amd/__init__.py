@@ -236,6 +236,7 @@ def lib():
     f("psdc_pack_readout", i32, [H, C.c_void_p, sz, C.POINTER(sz)])
     f("psdc_pack_init", i32, [C.c_void_p, sz, u32, C.c_float, C.c_float, sz, u32])
     f("psdc_pack_channel", i32, [C.c_void_p, sz, u32, u32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64), fp])
+    f("psdc_pack_pad", i32, [C.c_void_p, sz, C.c_void_p, sz, u32])
     f("psdc_unpack_info", i32, [C.c_void_p, sz, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)])
     f("psdc_unpack_stitch", i32, [C.c_void_p, sz, u32, i32, u32, i32, fp, sz, C.POINTER(sz), C.POINTER(_CBreak), sz,
                                   C.POINTER(sz)])
@@ -303,7 +304,7 @@ EXPORTS = [
     "psdc_stage_get_gain", "psdc_stage_get_buf", "psdc_stage_last_error",
     "psdc_create_window", "psdc_window_get", "psdc_window_table", "psdc_stage_create_window", "psdc_stitch_window",
     "psdc_readout_bytes", "psdc_pack_readout", "psdc_unpack_info", "psdc_unpack_stitch",
-    "psdc_pack_init", "psdc_pack_channel",
+    "psdc_pack_init", "psdc_pack_channel", "psdc_pack_pad",
 ]
 
 
@@ -726,6 +727,21 @@ def pack_record(n, channels, window=Window.HANN, rows=None):
         if rc < 0:
             _raise(rc)
     return buf
+
+
+def pack_pad(rec, rows):
+    """psdc_pack_pad: `rec` as a record of `rows` channels (the added ones empty) -- equal blocks for a gather."""
+    b = np.ascontiguousarray(np.frombuffer(rec, dtype=np.uint8))
+    if b.size < 32:
+        _raise(ERR_ARG)
+    n, nc = (int(v) for v in np.frombuffer(b[8:16].tobytes(), np.uint32))  # header {magic, version, n, n_channels, ...}
+    if rows == nc:
+        return b
+    out = np.empty(lib().psdc_readout_bytes(n, rows), dtype=np.uint8)
+    rc = lib().psdc_pack_pad(b.ctypes.data_as(C.c_void_p), b.size, out.ctypes.data_as(C.c_void_p), out.size, rows)
+    if rc < 0:
+        _raise(rc)
+    return out
 
 
 def unpack_info(buf, channel=0):

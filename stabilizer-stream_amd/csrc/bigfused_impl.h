@@ -197,12 +197,36 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     for (int v = 0; v < VT; ++v) {
         const float4 *c = cp + THREADS * v;
         const unsigned s = sp + 4u * THREADS * v;
+#if PSDK_HOIST_FIRST
+        if (FRAMES && fr) {
+            auto fp = [&](int k) {
+                const unsigned si = s + 4u * (unsigned)k;
+                const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+            };
+            ga[v][0] = fp(0);
+            ga[v][1] = fp(TEAM);
+            gb[v][0] = fp(2 * TEAM);
+            gb[v][1] = fp(3 * TEAM);
+            gc[v][0] = fp(N / 4);
+            gc[v][1] = fp(N / 4 + TEAM);
+        } else {
+            ga[v][0] = c[0];
+            ga[v][1] = c[TEAM];
+            gb[v][0] = c[2 * TEAM];
+            gb[v][1] = c[3 * TEAM];
+            gc[v][0] = c[N / 4];
+            gc[v][1] = c[N / 4 + TEAM];
+        }
+#else
         ga[v][0] = piece(c, s, 0);
         ga[v][1] = piece(c, s, TEAM);
         gb[v][0] = piece(c, s, 2 * TEAM);
         gb[v][1] = piece(c, s, 3 * TEAM);
         gc[v][0] = piece(c, s, N / 4);
         gc[v][1] = piece(c, s, N / 4 + TEAM);
+#endif
     }
 #pragma unroll
     for (int v = 0; v < VT; ++v) {

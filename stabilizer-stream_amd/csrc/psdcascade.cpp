@@ -2249,13 +2249,33 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
     // -- which frames are ingested is known, and reported, when the call returns, as the reference's per-frame `?` does
     // (src/source.rs:139) -- costs the device no idle time.  Four words come back through pinned memory: {~(first bad frame
     // << 2 | error) or 0, batches received, sequence gaps, first seq | next seq << 32}.
-    if (!h->d_scan) {
-        HIPCHK(h, hipMalloc(&h->d_scan, 5 * sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(h->d_scan, 0, 5 * sizeof(unsigned long long)));
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_scan), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!h->d_scan || !h->h_scan || !h->scan_stream) {
+        // built into locals and committed to the handle only when every step has succeeded: a half-built state (accumulators
+        // not zeroed, no pinned result words, the null stream) must never reach the verdict launch
+        unsigned long long *d_scan = nullptr, *h_scan = nullptr;
+        hipStream_t scan_stream = nullptr;
         int lo = 0, hi = 0;
-        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi)); // (hi = the numerically lowest = greatest priority)
-        HIPCHK(h, hipStreamCreateWithPriority(&h->scan_stream, hipStreamNonBlocking, hi));
+        hipError_t e = hipMalloc(&d_scan, 5 * sizeof(unsigned long long));
+        if (e == hipSuccess)
+            e = hipMemset(d_scan, 0, 5 * sizeof(unsigned long long));
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void **>(&h_scan), 4 * sizeof(unsigned long long), hipHostMallocDefault);
+        if (e == hipSuccess)
+            e = hipDeviceGetStreamPriorityRange(&lo, &hi); // (hi = the numerically lowest = greatest priority)
+        if (e == hipSuccess)
+            e = hipStreamCreateWithPriority(&scan_stream, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) {
+            if (scan_stream)
+                (void)hipStreamDestroy(scan_stream);
+            if (h_scan)
+                (void)hipHostFree(h_scan);
+            if (d_scan)
+                (void)hipFree(d_scan);
+            HIPCHK(h, e);
+        }
+        h->d_scan = d_scan;
+        h->h_scan = h_scan;
+        h->scan_stream = scan_stream;
     }
     const unsigned long long *res = h->h_scan;
     auto scan = [&](size_t n_loss, bool check) -> int {
@@ -2292,7 +2312,10 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
     if (good && batches > 0) {
         h->idle = false;
         const size_t per_frame = (size_t)batches * 8; // samples per trace and frame
-        const bool in_place_ok = fused_frames_supported((int)h->n) && fused_window(h);
+        // (the in-place kernels read wire words with 8-, 4- and 2-byte loads at offsets that are aligned relative to the
+        // base only: a base that is not a multiple of 8 takes the byte-wise decode kernel, as the verdict scan does)
+        const bool in_place_ok = fused_frames_supported((int)h->n) && fused_window(h) && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0 &&
+                                 frame_size % 8 == 0;
         // pieces of <= FSPAN_MAX_SAMPLES samples per trace (the kernels' cell arithmetic) / 2^24 on the decode path
         const size_t piece_frames = std::max<size_t>(1, (in_place_ok ? (size_t)FSPAN_MAX_SAMPLES : ((size_t)1 << 24)) / per_frame);
         for (size_t f0 = 0; f0 < good; f0 += piece_frames) {
@@ -2759,13 +2782,22 @@ struct PackStage {
 size_t pack_row_floats(uint32_t n) { return ((size_t)n / 2 + 1 + 1) & ~(size_t)1; }
 size_t pack_channel_bytes(uint32_t n) { return 8 + sizeof(PackStage) * MAX_STAGES + sizeof(float) * MAX_STAGES * pack_row_floats(n); }
 
-// header + bounds of a record; nullptr (and the error recorded) if it is not one
+// header + bounds of a record; nullptr (and the error recorded) if it is not one.  A record is documented to arrive over ANY
+// transport, so nothing in it is trusted: every field is held to the range the library itself can produce BEFORE it enters a size
+// computation (n a supported FFT size -- psdc_pack_init also admits the small powers of two the host-only tests use --,
+// n_channels <= 4096 as in psdc_create, overlap < n), and the length test is a division, which cannot wrap.
+constexpr uint32_t PACK_MAX_N = 16384, PACK_MAX_CHANNELS = 4096;
+bool pack_dims_ok(uint32_t n, uint32_t n_channels, uint64_t overlap)
+{
+    return n >= 2 && n <= PACK_MAX_N && n_channels <= PACK_MAX_CHANNELS && overlap < n;
+}
 const PackHeader *pack_check(const void *buf, size_t len, uint32_t channel)
 {
     const PackHeader *hd = static_cast<const PackHeader *>(buf);
-    if (!buf || len < sizeof(PackHeader) || hd->magic != PACK_MAGIC || hd->version != PACK_VERSION || hd->n < 2 ||
-        len < sizeof(PackHeader) + (size_t)hd->n_channels * pack_channel_bytes(hd->n)) {
-        fail(nullptr, PSDC_ERR_ARG, "not a packed read-out (psdc_pack_readout) or truncated");
+    if (!buf || len < sizeof(PackHeader) || hd->magic != PACK_MAGIC || hd->version != PACK_VERSION ||
+        !pack_dims_ok(hd->n, hd->n_channels, hd->overlap) || !(hd->power > 0.0f) || !(hd->nenbw > 0.0f) ||
+        (hd->n_channels && (len - sizeof(PackHeader)) / pack_channel_bytes(hd->n) < hd->n_channels)) {
+        fail(nullptr, PSDC_ERR_ARG, "not a packed read-out (psdc_pack_readout), truncated, or fields out of range");
         return nullptr;
     }
     if (channel >= hd->n_channels) {
@@ -2781,12 +2813,14 @@ extern "C" {
 
 size_t psdc_readout_bytes(uint32_t n, uint32_t n_channels)
 {
+    if (!pack_dims_ok(n, n_channels, 0)) // (0: no record of such dimensions exists)
+        return 0;
     return sizeof(PackHeader) + (size_t)n_channels * pack_channel_bytes(n);
 }
 
 int psdc_pack_init(void *buf, size_t cap, uint32_t n, float power, float nenbw, size_t overlap, uint32_t n_channels)
 {
-    if (!buf || n < 2 || overlap >= n || cap < psdc_readout_bytes(n, n_channels))
+    if (!buf || !pack_dims_ok(n, n_channels, overlap) || !(power > 0.0f) || !(nenbw > 0.0f) || cap < psdc_readout_bytes(n, n_channels))
         return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_init: bad arguments or buffer too small (psdc_readout_bytes)");
     memset(buf, 0, psdc_readout_bytes(n, n_channels));
     const PackHeader hd{PACK_MAGIC, PACK_VERSION, n, n_channels, power, nenbw, (uint32_t)overlap, 0};
@@ -2854,6 +2888,25 @@ int psdc_pack_readout(psdc_handle *h, void *buf, size_t cap, size_t *len)
     return PSDC_OK;
 }
 
+int psdc_pack_pad(const void *rec, size_t len, void *out, size_t cap, uint32_t n_channels)
+{
+    const PackHeader *hd = static_cast<const PackHeader *>(rec);
+    if (hd && len >= sizeof(PackHeader) && hd->n_channels == 0 && hd->magic == PACK_MAGIC && hd->version == PACK_VERSION &&
+        pack_dims_ok(hd->n, 0, hd->overlap))
+        ; // (a record of no channels -- a rank that owns none -- pads like any other)
+    else if (!pack_check(rec, len, 0))
+        return PSDC_ERR_ARG;
+    const size_t own = psdc_readout_bytes(hd->n, hd->n_channels), need = psdc_readout_bytes(hd->n, n_channels);
+    if (!out || out == rec || n_channels < hd->n_channels || need == 0 || cap < need)
+        return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_pad: fewer channels than the record holds, or buffer too small (psdc_readout_bytes)");
+    memcpy(out, rec, own);
+    memset(static_cast<char *>(out) + own, 0, need - own); // empty channels: no stages
+    PackHeader nh = *hd;
+    nh.n_channels = n_channels;
+    memcpy(out, &nh, sizeof(nh));
+    return PSDC_OK;
+}
+
 int psdc_unpack_info(const void *buf, size_t len, uint32_t channel, uint32_t *n, uint32_t *n_channels, uint32_t *n_stages)
 {
     const PackHeader *hd = pack_check(buf, len, channel);
@@ -2885,7 +2938,12 @@ int psdc_unpack_stitch(const void *buf, size_t len, uint32_t channel, int keep_o
     const size_t bins = hd->n / 2 + 1, row = pack_row_floats(hd->n);
     uint32_t counts[MAX_STAGES], avgs[MAX_STAGES];
     uint64_t counts64[MAX_STAGES], pend[MAX_STAGES];
-    std::vector<float> spectra((size_t)ns * bins);
+    std::vector<float> spectra;
+    try { // (nothing unwinds across the ABI; ns <= 16 and bins <= 8193 here, so this is 512 KiB at most)
+        spectra.resize((size_t)ns * bins);
+    } catch (const std::bad_alloc &) {
+        return fail(nullptr, PSDC_ERR_NOMEM, "psdc_unpack_stitch: out of memory");
+    }
     for (uint32_t k = 0; k < ns; ++k) {
         counts64[k] = ps[k].count64;
         counts[k] = count_report(ps[k].count64);

@@ -49,6 +49,7 @@ extern "C" {
                           device: c_int) -> *mut PsdcHandle;
     fn psdc_readout_bytes(n: u32, n_channels: u32) -> usize;
     fn psdc_pack_readout(h: *mut PsdcHandle, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
+    fn psdc_pack_pad(rec: *const c_void, len: usize, out: *mut c_void, cap: usize, n_channels: u32) -> c_int;
     fn psdc_unpack_stitch(
         buf: *const c_void, len: usize, channel: u32, keep_overlap: c_int, min_count: u32, keep_transition_band: c_int,
         psd_out: *mut f32, psd_cap: usize, psd_len: *mut usize,
@@ -181,6 +182,20 @@ pub fn psd_from_readout<const N: usize>(record: &[u8], opts: &MergeOpts) -> (Vec
     }
     p.truncate(plen);
     (p, b[..nb].iter().map(to_break).collect())
+}
+
+/// A gathered block must have the same size on every shard: `record` as a record of `n_channels` channels, the added
+/// ones empty (`psdc_pack_pad`; shards whose channel counts differ pad to the largest).
+pub fn pad_readout<const N: usize>(record: &[u8], n_channels: u32) -> Vec<u8> {
+    let mut out = vec![0u8; unsafe { psdc_readout_bytes(N as u32, n_channels) }];
+    let rc = unsafe {
+        psdc_pack_pad(record.as_ptr() as *const c_void, record.len(), out.as_mut_ptr() as *mut c_void, out.len(), n_channels)
+    };
+    if rc < 0 {
+        let msg = unsafe { CStr::from_ptr(psdc_last_error(std::ptr::null())) };
+        panic!("psdcascade: {}", msg.to_string_lossy());
+    }
+    out
 }
 
 impl<const N: usize> Default for PsdCascade<N> {

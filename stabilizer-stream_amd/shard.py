@@ -25,11 +25,13 @@ def pack_readout(bank, n_local, n, pkg=None, pad_to=None):
     PsdCascadeBank packs itself in the library (one flush, one copy per channel); anything that only
     duck-types the read-out accessors (a stand-in bank in the CPU tests) goes through psdc_pack_channel."""
     rows = max(n_local, pad_to or 0)
-    if hasattr(bank, "pack_readout") and rows == n_local == bank.n_channels:
-        return bank.pack_readout()
     if pkg is None:
         import sys
         pkg = sys.modules["stabilizer_stream_amd"]
+    if hasattr(bank, "pack_readout") and n_local == bank.n_channels:
+        # (always the library's own record, padded as bytes: the per-channel accessors below report the u32-saturated
+        # count, which parts company with psd()'s 64-bit normalisation past 2^32 segments)
+        return pkg.pack_pad(bank.pack_readout(), rows)
     chans = []
     for c in range(n_local):
         if hasattr(bank, "read_channel"):

@@ -242,6 +242,13 @@ def test_packed_record_roundtrip_and_64_bit_counts(pkg, ora):
             q, bq = pkg.unpack_stitch(rec, c, opts)
             assert np.array_equal(p, q, equal_nan=True) and br == bq
     assert pkg.unpack_info(rec, 4) == (n, 5, 0) and pkg.unpack_stitch(rec, 4)[0].size == 0  # padding channels are empty
+    # psdc_pack_pad: the unpadded record widened as bytes is the padded record, bit for bit (what shard.pack_readout does
+    # with a bank's own psdc_pack_readout record when shards are uneven)
+    rec3 = pkg.pack_record(n, chans)
+    assert pkg.unpack_info(rec3, 0)[1] == 3 and np.array_equal(pkg.pack_pad(rec3, 5), rec) and pkg.pack_pad(rec3, 3) is not None
+    with pytest.raises(pkg.PsdError):
+        pkg.pack_pad(rec, 3)  # cannot drop channels
+    assert pkg.unpack_info(pkg.pack_pad(pkg.pack_record(n, []), 2), 1) == (n, 2, 0)  # a rank that owns no channel
     with pytest.raises(pkg.PsdError):
         pkg.unpack_stitch(rec[:100], 0)
     # past 2^32 segments
@@ -258,3 +265,66 @@ def test_packed_record_roundtrip_and_64_bit_counts(pkg, ora):
     assert np.allclose(q[sl], expect, rtol=1e-6)
     psat, _ = pkg.stitch(n, [0xFFFFFFFF] + list(counts[1:]), avgs, pend, sp)  # what a u32 gather would have given
     assert not np.allclose(psat[sl], q[sl], rtol=1e-3)
+
+
+def test_packed_record_rejects_hostile_headers(pkg):
+    """A packed read-out may arrive over any transport: psdc_unpack_* must hold every header field to the range the
+    library can produce before it enters a size computation (the round-3 advisor's case: n = 2^31 with
+    n_channels = 2^28 wraps `n_channels * bytes_per_channel` in 64 bits, the length test passes and the channel
+    pointer leaves the buffer), never read out of bounds and never let an exception cross the ABI."""
+    import struct
+    n = 64
+    sp = np.ones((2, n // 2 + 1), np.float32)
+    rec = pkg.pack_record(n, [([9, 1], [0xFFFFFFFF] * 2, [3, 5], sp)], rows=2)
+    assert pkg.unpack_info(rec, 0) == (n, 2, 2)
+
+    def with_header(**kw):
+        f = dict(zip(("magic", "version", "n", "n_channels", "power", "nenbw", "overlap", "kind"),
+                     struct.unpack("<IIIIffII", rec[:32].tobytes())))
+        f.update(kw)
+        b = rec.copy()
+        b[:32] = np.frombuffer(struct.pack("<IIIIffII", *f.values()), np.uint8)
+        return b
+
+    hostile = [
+        with_header(n=1 << 31, n_channels=1 << 28),   # product wraps to a small number
+        with_header(n=1 << 31, n_channels=2),
+        with_header(n=0x80000040, n_channels=1 << 27),
+        with_header(n=1 << 20),                        # beyond any FFT size the library has
+        with_header(n=1),
+        with_header(n_channels=0xFFFFFFFF),
+        with_header(n_channels=4097),
+        with_header(n_channels=3),                     # one more channel than the bytes hold
+        with_header(overlap=n), with_header(overlap=0xFFFFFFFF),
+        with_header(power=0.0), with_header(nenbw=float("nan")),
+        with_header(magic=0x12345678), with_header(version=99),
+        rec[:31], rec[:32], rec[: rec.size - 1],
+    ]
+    for b in hostile:
+        for ch in (0, 1, 7, 0xFFFFFFFF):
+            with pytest.raises(pkg.PsdError):
+                pkg.unpack_info(b, ch)
+            with pytest.raises(pkg.PsdError):
+                pkg.unpack_stitch(b, ch)
+    # a stage count beyond the slots of a channel is refused too (it indexes the stage table)
+    b = rec.copy()
+    b[32:36] = np.frombuffer(struct.pack("<I", 17), np.uint8)
+    with pytest.raises(pkg.PsdError):
+        pkg.unpack_stitch(b, 0)
+    # the intact record still reads
+    assert pkg.unpack_stitch(rec, 0)[0].size > 0
+    for bad in ((1 << 31, 1 << 28), (64, 4097), (1 << 20, 1)):
+        with pytest.raises(pkg.PsdError):
+            pkg.pack_record(bad[0], [], rows=bad[1])
+
+
+@pytest.mark.timeout(900)
+def test_kernels_pass_the_machine_verifier():
+    """`make verify` (csrc/Makefile): every kernel TU through the gfx950 backend with LLVM's machine verifier on after
+    each pass.  It is the check that names the miscompile round 3 met in one kernel variant (si-form-memory-clauses left
+    a truncated live subrange; the allocator then reused the VGPR of a live sample -- DESIGN.md section 4): a restructured
+    kernel that trips it again fails HERE, on the CPU, instead of as wrong spectra in one template variant on the GPU."""
+    csrc = os.path.join(ROOT, "stabilizer-stream_amd", "csrc")
+    r = subprocess.run(["make", "-j8", "-C", csrc, "verify"], capture_output=True, text=True, timeout=880)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "every kernel TU clean" in r.stdout
