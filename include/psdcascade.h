@@ -20,6 +20,14 @@
  *     trace, src/bin/psd.rs:174-182) that are batched onto one GPU.
  *   - all sample data is IEEE f32, native endian (src/bin/stream_to_raw.rs:24-25).
  *   - there is NO CPU fallback: without a usable HIP device `psdc_create` fails.
+ *   - call chunking: like the reference (src/psd.rs:196-208) every result is a function of the CONCATENATED stream of a
+ *     channel.  Counters (stage count, count, pending, processed, Break fields, frequencies, Loss) are exactly independent of
+ *     how the stream was cut into process() calls.  Spectra are independent of it only to rounding: the reference adds
+ *     segment after segment into one f32 accumulator and is bit-identical under any chunking; here the segments a call brings
+ *     are summed in groups (per workgroup run in f32, across runs in f64, one f32 add into the accumulator per round) whose
+ *     boundaries follow the calls, so two chunkings of one stream agree to <= 2e-6 relative per bin (asserted by
+ *     tests/test_gpu_parity.py::test_chunking_invariance), while the same stream fed by the same calls is bit-reproducible.
+ *     Either grouping is closer to the exact sum than the reference's sequential f32 accumulation.
  */
 #ifndef PSDCASCADE_H
 #define PSDCASCADE_H
@@ -170,7 +178,7 @@ int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count);
 /* PsdCascade::process(&[f32]) (src/psd.rs:456-468) for one channel.  `x` is host
  * memory and is copied before returning.  GPU work may be deferred until
  * PSDC_OPT_QUANTUM samples are buffered or a read-out/flush happens; results
- * depend only on the concatenated stream, not on call chunking. */
+ * depend only on the concatenated stream, not on call chunking (counters exactly, spectra to rounding: Conventions). */
 int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len);
 
 /* Same, but `d_x` is device memory on the handle's device and is read in place
