@@ -62,7 +62,8 @@ def gpu_required():
 #   (a) over the bins whose tolerance the extra terms more than double (an a-priori set), the GPU's rms error must be
 #       no larger than the f32 reference's own, or meet the pure 1e-5 there in the rms sense;
 #   (b) EVERY bin whose error exceeds the pure 1e-5 bound -- wherever it sits -- may use no more of its widened
-#       tolerance than EXCESS_K (= 6) x what the f32 reference's own arithmetic uses at ITS worst bin of the same spectrum
+#       tolerance than EXCESS_K (= 4; x sqrt 2 at the two real-valued bins, see below) x what the f32 reference's own arithmetic
+#       (the worse of two independent f32 restatements) uses at ITS worst bin of the same spectrum
 #       (err / tol against max_k e32_k / tol_k).  The comparison is with the reference's worst bin, not with the same
 #       bin: on signals that need the widening (a step of 1e5 sigma inside a segment, a tone 60 dB above the noise) the
 #       errors of an f32 FFT are outliers at bins its radix structure picks, and the GPU's (4, 16, ..., 16) passes pick
@@ -73,9 +74,27 @@ def gpu_required():
 RTOL = 1e-5
 ATOL_FRAC = 1e-6
 DYN = 5e-7
-EXCESS_K = 6.0  # (two samples of heavy-tailed rounding errors: the fuzz campaigns' extremes over ~12 000 spectra are 4.1x and 5.1x, both the
-#                 Nyquist bin of a stage with two or three averages under finite averaging, each below 0.2 of its widened tolerance;
-#                 the suite's own closest is 3.06x)
+EXCESS_K = 4.0
+# Round 3 had raised the cap to 6 after two campaign outliers (4.1x and 5.1x among ~12 000 spectra); round 4 explains them and
+# puts it back.  Both were the NYQUIST bin of a stage with two or three averages, and both times that bin was ~1e4 below the
+# spectrum's maximum.  Two things meet there:
+#  (1) Bins 0 and N/2 of a real segment are REAL-valued: their per-segment power is chi-square with ONE degree of freedom
+#      (density ~ 1/sqrt(p) at 0), so with 2-3 averages such a bin falls 1e4 below the spectrum's maximum with probability
+#      ~ sqrt(1e-4)^count -- rare but present in a campaign -- where a complex bin needs 1e-4^count.  There the DYN term carries
+#      the tolerance, the reference's worst bin is usually that SAME bin, and rule (b) degenerates into the ratio of two single
+#      rounding-error samples.
+#  (2) At exactly these bins the two-for-one transform (z = x_a + i x_b) has twice the rounding-error
+#      VARIANCE of an FFT per segment of the same arithmetic quality: with e the complex rounding error of a bin (E|e|^2 = s^2
+#      for the reference's N-point transform of one segment, 2 s^2 for the transform of z, which carries both segments' energy),
+#      the reference reads |X_a|^2 + |X_b|^2 with error 2 Re(X_a* e_a) + 2 Re(X_b* e_b), variance 2 s^2 S at every bin
+#      (S = |X_a|^2 + |X_b|^2; at a real bin only Re e counts but the factor 2 stays).  The GPU reads 1/2 (|Z[k]|^2 + |Z[N-k]|^2)
+#      with error Re(Z[k]* e[k]) + Re(Z[N-k]* e[N-k]): variance (2 s^2 / 2)(|Z[k]|^2 + |Z[N-k]|^2) = 2 s^2 S -- the same -- at
+#      every k except k = 0 and k = N/2, where the two terms are ONE bin: error 2 Re(Z* e), variance 4 s^2 S.
+#      So the cap at the real-valued bins is EXCESS_K * sqrt(2) (callers name them: `real_bins`).
+# And the yardstick is no longer one realisation of f32 rounding but the worse of TWO independent f32 restatements of the
+# reference's arithmetic (the radix-2 FFT every parity test sees and the radix-4 Stockham one, oracle set_fast_fft): both are
+# "the reference in f32"; rustfft's own rounding is a third such realisation.
+REAL_BIN_FACTOR = 2.0 ** 0.5
 WORST = {"pure": (0.0, ""), "widened": (0.0, ""), "excess_vs_f32": (0.0, ""), "unjustified": (0.0, "")}
 COUNTS = {"pure": 0, "justified": 0, "unjustified": 0, "excess_bins": 0}
 
@@ -90,17 +109,22 @@ def _note(kind, value, text):
         WORST[kind] = (value, text)
 
 
-def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN, pure=False, ref_f32=None):
+def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN, pure=False, ref_f32=None, real_bins=None):
+    """ref_f32: the f32 restatement's result, or a list of results of independent f32 restatements.
+    real_bins: indices (into `ref`) of bins 0 / N/2 of a stage -- the real-valued bins, see EXCESS_K."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
     if ref.size == 0:
         return 0.0
+    kcap = np.full(ref.shape, EXCESS_K)
+    if real_bins is not None:
+        kcap[[b for b in real_bins if 0 <= b < ref.size]] *= REAL_BIN_FACTOR
     # a stage with count 0 included by min_count = 0 reads 0 * (1/0) = NaN, in the reference too
     both_nan = np.isnan(got) & np.isnan(ref)
     assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
     keep = ~both_nan
-    got, ref = got[keep], ref[keep]
+    got, ref, kcap = got[keep], ref[keep], kcap[keep]
     if ref.size == 0:
         return 0.0
     base = rtol * np.abs(ref)
@@ -122,23 +146,27 @@ def assert_psd_close(got, ref, what="", rtol=RTOL, atol_frac=ATOL_FRAC, dyn=DYN,
     excess = err > base      # the bins that actually exceed the pure bound
     if ref_f32 is not None:
         COUNTS["justified"] += 1
-        e32 = np.abs(np.asarray(ref_f32, dtype=np.float64)[keep] - ref)
+        refs32 = ref_f32 if isinstance(ref_f32, (list, tuple)) else [ref_f32]
+        e32s = [np.abs(np.asarray(r_, dtype=np.float64)[keep] - ref) for r_ in refs32]
+        e32 = e32s[int(np.argmax([float(np.max(e_ / np.maximum(tol, 1e-300))) for e_ in e32s]))]  # the one with the worse worst bin
         rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
         if np.any(wide):
-            g, r, p = rms(err[wide]), rms(e32[wide]), rms(base[wide])
+            g, r, p = rms(err[wide]), max(rms(e_[wide]) for e_ in e32s), rms(base[wide])
             assert g <= max(r, p), (f"{what}: on the {int(wide.sum())} widened bins the GPU's rms error {g:.3g} exceeds both the "
                                     f"f32 reference arithmetic's {r:.3g} and the pure 1e-5 level {p:.3g}")
         if np.any(excess):
             COUNTS["excess_bins"] += int(excess.sum())
             used_g, used_f = err / np.maximum(tol, 1e-300), e32 / np.maximum(tol, 1e-300)
             f_worst = float(np.max(used_f))
-            cap = np.maximum(EXCESS_K * f_worst, base / np.maximum(tol, 1e-300))
+            cap = np.maximum(kcap * f_worst, base / np.maximum(tol, 1e-300))
             k = int(np.argmax(np.where(excess, used_g, 0.0)))
             assert np.all(used_g[excess] <= cap[excess]), (
                 f"{what}: bin {k} exceeds the pure 1e-5 bound (rel {relv[k]:.3g}) using {used_g[k]:.3g} of its widened tolerance, "
-                f"more than {EXCESS_K}x the {f_worst:.3g} the f32 reference arithmetic uses at its worst bin "
+                f"more than {kcap[k]:.3g}x the {f_worst:.3g} the f32 reference arithmetic uses at its worst bin "
                 f"({int(np.argmax(used_f))}) of this spectrum")
-            ratio = float(used_g[k] / max(f_worst, 1e-300))
+            kr = int(np.argmax(np.where(excess, used_g / kcap, 0.0)))  # closest to its own cap
+            ratio = float(used_g[kr] / max(f_worst, 1e-300)) * EXCESS_K / float(kcap[kr])  # (in units of the plain cap)
+            k = kr
             _note("excess_vs_f32", ratio, f"{what}, bin {k}: rel err {relv[k]:.3g}; the f32 reference's worst bin {int(np.argmax(used_f))} "
                                           f"has rel err {float(e32[int(np.argmax(used_f))] / max(abs(ref[int(np.argmax(used_f))]), 1e-300)):.3g}")
             ke = int(np.argmax(np.where(excess, relv, 0.0)))
