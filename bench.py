@@ -27,9 +27,81 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP32_VALU_PEAK_TFLOPS = 157.3
+FP32_VALU_PEAK_TFLOPS = 157.3  # PACKED f32 FMA: 256 CUs x 4 SIMDs x 32 lane-results/clk x 2 flop x 2.4 GHz
+# What the fused kernels are built from is scalar (non-packed) f32 VALU -- the build disables packed f32 ops (csrc/Makefile NOPK:
+# a packed op is two passes through the SIMD and costs register pairing).  tools/probes/valu_rate.cpp measures the rate the
+# SIMDs sustain for dependent-free v_fma_f32 at four wavefronts per SIMD: ~22 lane-results per clock and SIMD (26 for
+# v_pk_fma_f32, of the 32 the packed peak assumes).  The scalar-FMA ceiling at the nominal 2.4 GHz:
+SCALAR_FMA_LANES_PER_CLK_SIMD = 22.0
+FP32_SCALAR_FMA_PEAK_TFLOPS = 256 * 4 * SCALAR_FMA_LANES_PER_CLK_SIMD * 2 * 2.4e9 / 1e12  # = 108.1
+BINDING = ("fp32 VALU issue + LDS issue, at the package power limit (SQ counters: VALU active ~0.38, LDS-issue stall ~0.23 of wave "
+           "time, ~1350 W at ~2.15 GHz); HBM is NOT the binding resource -- `frac` prices the kernel against HBM because "
+           "BASELINE.json's metric asks for that")
 ALG_BYTES_PER_SAMPLE = 4.0   # each raw f32 sample crosses HBM once
 ALG_FLOP_PER_SAMPLE = {1024: 78.0, 4096: 89.0, 16384: 100.0}
+
+
+class DeviceState:
+    """Engine clock and socket power of THIS process's GPU, sampled from the amdgpu hwmon files (sysfs reads: no child process,
+    nothing on the GPU) by a thread for as long as the `with` block runs.  The card is found through the PCI bus id HIP
+    reports; None fields where the box does not expose the files."""
+
+    def __init__(self, torch, device, period_s=0.005):
+        import glob
+        self.period, self.rows, self._stop, self._th = period_s, [], False, None
+        self.fp = self.ff = self.cap = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw:
+                for name in ("power1_input", "power1_average"):
+                    if os.path.exists(os.path.join(hw[0], name)):
+                        self.fp = os.path.join(hw[0], name)
+                        break
+                if os.path.exists(os.path.join(hw[0], "freq1_input")):
+                    self.ff = os.path.join(hw[0], "freq1_input")
+                try:
+                    self.cap = int(open(os.path.join(hw[0], "power1_cap")).read()) / 1e6
+                except (OSError, ValueError):
+                    pass
+                self.src = f"{hw[0]} ({bdf})"
+            else:
+                self.src = f"no hwmon under /sys/bus/pci/devices/{bdf}"
+        except Exception as e:  # noqa: BLE001 -- a diagnostic, never the reason a bench fails
+            self.src = f"unavailable: {e}"
+
+    def _read(self, path):
+        try:
+            return int(open(path).read())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.rows.append((self._read(self.ff), self._read(self.fp)))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.fp or self.ff:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        f = [r[0] / 1e6 for r in self.rows if r[0]]
+        w = [r[1] / 1e6 for r in self.rows if r[1]]
+        return {"sclk_mhz_mean": sum(f) / len(f) if f else None, "sclk_mhz_min": min(f) if f else None,
+                "sclk_mhz_max": max(f) if f else None, "sclk_mhz_peak_nominal": 2400,
+                "socket_power_w_mean": sum(w) / len(w) if w else None, "socket_power_w_max": max(w) if w else None,
+                "socket_power_cap_w": self.cap, "samples": len(self.rows), "period_ms": self.period * 1e3, "source": self.src,
+                "note": "sampled during the timed region (hwmon freq1_input = sclk, power1_input = socket power)"}
 
 
 def cpu_baseline(n, seconds=12.0, threads=1):
@@ -142,9 +214,44 @@ def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None):
     ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
     return {"value": passes * T / dt / 1e6, "unit": "MS/s",
             "workload": f"1-channel raw f32, PsdCascade N={n}, {passes} passes over 2^{log2_batch} samples resident in HBM ({T * 4 >> 20} MiB), {ns} stages",
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "binding": BINDING, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "end_to_end_frac": ALG_BYTES_PER_SAMPLE * passes * T / dt / 1e9 / HBM_PEAK_GBPS,
                          "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"])}}
+
+
+class FrameReplay:
+    """A frame stream replayed from two copies of one buffer with the sequence numbers moving on: a real stream's `seq` advances
+    by `batches` per frame (src/de/frame.rs:5-9), and Loss::update (src/loss.rs:11-26) counts a call whose first `seq` is not the
+    last call's next one as ~2^32 dropped batches -- which replaying ONE buffer did (round-3 record: `dropped` 5e13).  Call k reads
+    buffer k % 2; right after it has been handed over, the `seq` words of that buffer are moved on by two calls' worth on torch's
+    stream (4 bytes per header; the payload the in-place kernels may still be reading is not touched), long before call k + 2
+    waits for that event."""
+
+    def __init__(self, torch, frames_u8, frame_size, n_frames, batches):
+        self.torch, self.fs, self.nf, self.batches = torch, frame_size, n_frames, batches
+        hdr = frames_u8.reshape(n_frames, frame_size)[:, 4:8].copy().view("<u4").reshape(n_frames).astype(np.int64)
+        self.seq = [torch.from_numpy(((hdr + k * n_frames * batches) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).cuda() for k in range(2)]
+        self.buf = [torch.from_numpy(frames_u8).cuda() for _ in range(2)]
+        self.ev = [None, None]
+        self.k = 0
+        self._write(1)
+        torch.cuda.synchronize()
+
+    def _write(self, b):
+        v = self.buf[b].view(self.nf, self.fs)
+        v[:, 4:8] = self.seq[b].view(self.torch.uint8).view(self.nf, 4)
+        e = self.torch.cuda.Event()
+        e.record()
+        self.ev[b] = e
+
+    def feed(self, bank):
+        b = self.k & 1
+        if self.ev[b] is not None:
+            self.ev[b].synchronize()  # (recorded two calls ago)
+        bank.process_adcdac_frames_device(self.buf[b].data_ptr(), self.fs, self.nf)
+        self.seq[b] += 2 * self.nf * self.batches  # int32 arithmetic wraps like the u32 on the wire
+        self._write(b)
+        self.k += 1
 
 
 def side_leg_frames(pkg, torch, device, seconds, n=4096, batches=22, log2_per_trace=24):
@@ -154,18 +261,17 @@ def side_leg_frames(pkg, torch, device, seconds, n=4096, batches=22, log2_per_tr
     rng = np.random.default_rng(1)
     raw = np.clip(np.round(rng.standard_normal((4, nframes * batches * 8), dtype=np.float32) * 4096), -32768, 32767).astype(np.int16)
     data, fs = pkg.make_adcdac_frames(raw, batches)
-    d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
-    torch.cuda.synchronize()
+    rep = FrameReplay(torch, np.frombuffer(data, dtype=np.uint8).copy(), fs, nframes, batches)
     bank = pkg.PsdCascadeBank(n, 4, device=device)
     for _ in range(3):
-        bank.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+        rep.feed(bank)
     bank.sync()
     bank.configure(profile=True)
     t0 = time.perf_counter()
     calls = 0
     while time.perf_counter() - t0 < seconds:
         for _ in range(4):
-            bank.process_adcdac_frames_device(d.data_ptr(), fs, nframes)
+            rep.feed(bank)
         calls += 4
     ns = bank.num_stages(0)
     for c in range(4):
@@ -179,8 +285,10 @@ def side_leg_frames(pkg, torch, device, seconds, n=4096, batches=22, log2_per_tr
     ach = nbytes / kern_s / 1e9 if kern_s > 0 else 0.0
     return {"value": calls * raw.size / dt / 1e6, "unit": "MS/s (samples of the four traces)",
             "workload": f"BASELINE configs[2]: 4-trace AdcDac frames ({batches} batches, {fs} B) resident in HBM, PsdCascade N={n}, "
-                        f"{calls} calls of {nframes} frames (2^{log2_per_trace} samples per trace), {ns} stages; Loss {loss}",
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                        f"{calls} calls of {nframes} frames (2^{log2_per_trace} samples per trace) replayed from two buffers with `seq` "
+                        f"moving on, {ns} stages",
+            "loss": loss,
+            "roofline": {"bound": "hbm", "binding": BINDING, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "end_to_end_frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_sample": fs / (batches * 8.0 * 4),
                          "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"]),
                          "note": "achieved = n_frames x frame_size / time of the dominant (fused) launches; end_to_end_frac over wall time"}}
@@ -349,7 +457,8 @@ def main():
         rng = np.random.default_rng(1)
         raw = np.clip(np.round(rng.standard_normal((4, T), dtype=np.float32) * 4096), -32768, 32767).astype(np.int16)
         fr_data, fr_size = pkg.make_adcdac_frames(raw, FR_BATCHES)
-        bufs.append(torch.from_numpy(np.frombuffer(fr_data, dtype=np.uint8).copy()).cuda())
+        fr_bytes = np.frombuffer(fr_data, dtype=np.uint8).copy()
+        replays = {}
         del raw, fr_data
     else:
         for c in range(C):
@@ -361,8 +470,10 @@ def main():
     P = args.passes
 
     def feed(b):
-        if frames:
-            b.process_adcdac_frames_device(bufs[0].data_ptr(), fr_size, fr_n)
+        if frames:  # (one replay per cascade: the scratch cascade of the clock warm-up has a stream of its own)
+            if id(b) not in replays:
+                replays[id(b)] = FrameReplay(torch, fr_bytes, fr_size, fr_n, FR_BATCHES)
+            replays[id(b)].feed(b)
         else:
             for c in range(C):
                 b.process_device(c, bufs[c].data_ptr(), T)
@@ -407,6 +518,8 @@ def main():
             shard.gather_readout(dist, wrec, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     barrier()
     prof0 = bank.profile_read()  # launches of the warm-up (kept: rocprofv3 --stats sees them too)
+    dstate = DeviceState(torch, local_rank)
+    dstate.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -433,6 +546,7 @@ def main():
         t_read = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    dstate.__exit__()
     if os.environ.get("PSD_BENCH_DEBUG"):
         print(f"[debug] enqueue {host_enqueue_s*1e3:.2f} ms, +sync {t_sync*1e3:.2f} ms, +drain {t_drain*1e3:.2f} ms, +read_channel {t_rc*1e3:.2f} ms, "
               f"+pack {t_pack*1e3:.2f} ms, +readout {t_read*1e3:.2f} ms, "
@@ -477,8 +591,9 @@ def main():
                        "samples_per_step_per_channel": T * P,
                        "algorithmic_bytes_per_sample": alg_bps,
                        "stages": ns, "parallelism": f"channel-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "binding": BINDING, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
+                         "device_state": dstate.summary(),
                          # launches hold 1..PSDC_OPT_COALESCE spans of 2^log2_batch samples: both per-launch
                          # figures are for the AVERAGE launch of the timed region; the PMC traffic is measured
                          # per one-span launch (--coalesce 1) and scaled by the spans per launch
@@ -488,6 +603,8 @@ def main():
                          "traffic": (tr["hbm_bytes_per_launch"] * prof["stage0_samples"] / max(1, prof["launches"]) / (T * C)
                                      if tr else None),  # = traffic_from_profiles (the contract's field name)
                          "traffic_over_algorithmic": (tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]) if tr else None,
+                         # what the memory side actually moves: counter traffic / kernel time / peak (= frac x traffic_over_algorithmic)
+                         "counter_traffic_frac": (ach / HBM_PEAK_GBPS * tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]) if tr else None,
                          "traffic_source": (tr["round"] + " PMC passes (one-span launches), profiles/") if tr else None,
                          "algorithmic_bytes_per_launch": alg_bps * prof["stage0_samples"] / max(1, prof["launches"]),
                          "spans_per_launch": prof["stage0_samples"] / max(1, prof["launches"]) / (T * C),
@@ -499,6 +616,14 @@ def main():
             "compute_roofline": {"bound": "fp32_valu", "achieved": flop * msps * 1e6 / 1e12 / world,
                                  "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": flop * msps * 1e6 / 1e12 / world / FP32_VALU_PEAK_TFLOPS,
+                                 "peak_is": "packed f32 FMA (v_pk_fma_f32) at 2.4 GHz; the kernels issue scalar f32 VALU",
+                                 "scalar_fma_peak": FP32_SCALAR_FMA_PEAK_TFLOPS,
+                                 "frac_of_scalar_fma_peak": flop * msps * 1e6 / 1e12 / world / FP32_SCALAR_FMA_PEAK_TFLOPS,
+                                 "scalar_fma_peak_is": f"{SCALAR_FMA_LANES_PER_CLK_SIMD:g} lane-results/clk/SIMD sustained by v_fma_f32 at four "
+                                                       "wavefronts per SIMD (tools/probes/valu_rate.cpp) x 1024 SIMDs x 2 flop x 2.4 GHz; "
+                                                       "algorithmic flop count, so instruction overheads (DPP moves, address arithmetic, "
+                                                       "non-fused adds: ~820 VALU instructions per pair and wavefront for ~670 flop-instructions) "
+                                                       "and the sub-nominal clock both sit between this fraction and the VALU's busy fraction",
                                  "algorithmic_flop_per_sample": flop},
         }
         bank.close()
