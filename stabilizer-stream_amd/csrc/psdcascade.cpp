@@ -1045,7 +1045,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             batch_frames = batch_frames || fjobs[i].j.fspan >= 0;
         // (FRAME_RESERVE_BLOCKS slots of at least 256 threads' worth of registers each)
         const uint64_t reserve = (uint64_t)FRAME_RESERVE_BLOCKS * (uint64_t)std::max(1, 256 / std::max(1, fused_block_threads((int)h->n)));
-        const uint64_t cap = (uint64_t)fused_max_blocks((int)h->n) - (batch_frames ? reserve : 0u);
+        const uint64_t max_blocks = (uint64_t)fused_max_blocks((int)h->n);
+        const uint64_t cap_slots = max_blocks > reserve + 1 && batch_frames ? max_blocks - reserve : max_blocks;
         // Small jobs ride on top: a job whose one workgroup has at most a quarter of a full workgroup's work (the deep stages
         // of every channel: a handful of pairs per round) does not count against the capacity.  Its workgroup goes FIRST in
         // the grid, is resident for a few microseconds and leaves its slot to one of the surplus workgroups of the large
@@ -1055,10 +1056,15 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         static const bool no_oversub = getenv("PSDC_NO_OVERSUB") != nullptr; // (A/B aid)
         auto small_at = [&](uint64_t np, uint64_t r) { return !no_oversub && 4 * np <= r * teams; };
         auto plan_r = [&](uint64_t r_small) { // the smallest R whose LARGE jobs fit the capacity, given which jobs count as small
-            uint64_t pairs = 0;
+            uint64_t pairs = 0, nlarge = 0;
             for (size_t i = b0; i < b1; ++i)
-                if (!small_at((uint64_t)fjobs[i].j.npairs, r_small))
+                if (!small_at((uint64_t)fjobs[i].j.npairs, r_small)) {
                     pairs += (uint64_t)fjobs[i].j.npairs;
+                    ++nlarge;
+                }
+            // (every job holds at least one workgroup: with more large jobs than slots -- MAX_JOBS = 128 against >= 248 slots, so
+            // only under the CPU model's artificially small capacities -- the search below would never end)
+            const uint64_t cap = std::max<uint64_t>(cap_slots, nlarge);
             auto blocks_at = [&](uint64_t r) {
                 uint64_t nb = 0;
                 for (size_t i = b0; i < b1; ++i)

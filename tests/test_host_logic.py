@@ -63,6 +63,22 @@ def test_host_programs(pkg):
     assert m.group(1) == m.group(2) and m.group(3) == m.group(4), line
 
 
+@pytest.mark.timeout(900)
+def test_round_planner_on_the_cpu_under_sanitizers():
+    """tests/host/round_plan_check: the library's host runtime (csrc/psdcascade.cpp unchanged -- the round planner
+    advance_round, staging, frame ingest, read-outs) linked with a host model of the HIP runtime and of the kernels
+    (tests/host/sim/), built with -fsanitize=address,undefined.  The GPU fuzz campaigns' feeds are replayed; every address
+    the planner hands to a kernel is touched as the real kernel touches it, and every segment and every decimator output
+    of every stream must be produced exactly once (src/psd.rs:196-269).  tools/planner_mutations.sh shows that seeded
+    planner bugs are caught."""
+    host = os.path.join(ROOT, "tests", "host")
+    subprocess.run(["make", "-C", host, "round_plan_check"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    r = subprocess.run([os.path.join(host, "round_plan_check"), "1", "30"], capture_output=True, text=True, timeout=850, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "every segment and every decimator output exactly once" in r.stdout
+
+
 def test_cpp_source_mirror(pkg, tmp_path):
     """cpp/source.hpp, the C++ mirror of the reference's file-backed Source (src/source.rs:135-157): get() at the
     reference's granularity (512 raw samples / one frame per call, --repeat wrap), AdcDac decode on the host
