@@ -41,7 +41,7 @@ struct g8 {
 // Detrend + window + EWMA amplitude of one segment pair into the 16 FFT inputs of a lane (src/psd.rs:75-113, :211): slot m gets
 // sample n = tl + (N/16) m of segment a = (lo, up) in .re and of segment b = (up, nl) in .im.  Mean: lo and up arrive with the
 // pivot d.ob already subtracted (CENTRED, as in fused_common.h's window_pair), nl is raw.
-template <int N, int DETREND, bool EWMA>
+template <int N, int DETREND, bool EWMA, bool SINGLE = false>
 __device__ __forceinline__ void window_pair3(cf (&v)[16], int tl, const g8 &lo, const g8 &up, const g8 &nl, const float (&w)[16],
                                              const DetrendParams &d)
 {
@@ -66,11 +66,11 @@ __device__ __forceinline__ void window_pair3(cf (&v)[16], int tl, const g8 &lo, 
             xa *= d.ea;
             xb *= d.eb;
         }
-        v[m] = {xa, xb};
+        v[m] = {xa, SINGLE ? 0.0f : xb}; // (SINGLE: overlap 0, one segment per pair -- fused_common.h window_pair)
     }
 }
 
-template <int N, int DETREND, bool EWMA, bool FRAMES = false>
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
 __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused3_kernel(const FusedBatch batch,
                                                                            const float *__restrict__ win,
                                                                            const cf *__restrict__ tw0g)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + 2 * p0);
+            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
     }
     // the lane's twiddle seeds, held across the run (opaque per pair: see bigfused_impl.h)
     const typename T::Seeds sd_run = T::load_seeds(tp, tw0g);
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         if constexpr (EWMA) {
             if (job.ewma) {
                 dp.ea = eamp.next(job);
-                dp.eb = eamp.next(job);
+                if constexpr (!SINGLE)
+                    dp.eb = eamp.next(job);
             }
         }
         {
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
 #pragma unroll
             for (int m = 0; m < 16; ++m)
                 w[m] = (PSDK_ABL3 & 2048) ? 0.5f + dp.ea * (float)m : winp[tp + (N / 16) * m]; // (2048: timing only, no window loads)
-            window_pair3<N, DETREND, EWMA>(vv, tp, lo, up, nl, w, dp);
+            window_pair3<N, DETREND, EWMA, SINGLE>(vv, tp, lo, up, nl, w, dp);
         }
         {
             typename T::Seeds sd = sd_run;
@@ -468,6 +469,27 @@ hipError_t launch_bigfused3_n(const FusedBatch &b, const float *win, const cf *t
         else                                                                                      \
             hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
         break;
+#define PSDK_BIG3_SINGLE(D)                                                                                   \
+    case D:                                                                                                   \
+        if (ew_)                                                                                              \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
+        else                                                                                                  \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
+        break;
+    if (b.single) {
+        if (b.any_frames)
+            return hipErrorInvalidValue;
+        switch (b.detrend) {
+            PSDK_BIG3_SINGLE(0)
+            PSDK_BIG3_SINGLE(1)
+            PSDK_BIG3_SINGLE(2)
+            PSDK_BIG3_SINGLE(3)
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+#undef PSDK_BIG3_SINGLE
     switch (b.detrend) {
         PSDK_BIG3_CASE(0)
         PSDK_BIG3_CASE(1)

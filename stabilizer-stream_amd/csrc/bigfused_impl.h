@@ -78,7 +78,8 @@ struct BigGeo : FusedDec<N, NOX> {
 // the register group until the loads have landed and converted there (i16 -> f32 x LSB, DAC words offset binary, :28-35,
 // :64,:75) -- the four f32 streams of the traces never exist in memory.  Built as separate kernels: the f32-only launches
 // keep their instruction stream and registers.
-template <int N, int DETREND, bool EWMA, bool FRAMES = false>
+// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair).
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
 __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_kernel(const FusedBatch batch,
                                                                          const float *__restrict__ win,
                                                                          const cf *__restrict__ tw0g,
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + 2 * p0);
+            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
     }
 
     // The lane's own twiddle seeds (W_N^(4 tl); W_L1^s, W_L1^(4 s): fft_block.h) do not change from pair to pair: six registers
@@ -569,7 +570,8 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         if constexpr (EWMA) {
             if (job.ewma) {
                 dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
-                dp.eb = eamp.next(job);
+                if constexpr (!SINGLE)
+                    dp.eb = eamp.next(job);
             }
         }
         // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             } else {
                 sd[v] = T::load_seeds(tl, tw0p);
             }
-            window_pair<N, DETREND, EWMA, true>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
+            window_pair<N, DETREND, EWMA, true, SINGLE>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
                                           wq2, wq3, dp);
             // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
             // go one after the other between two barriers)
@@ -756,6 +758,27 @@ hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw
         else                                                                                      \
             hipExtLaunchKernelGGL((bigfused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
         break;
+#define PSDK_BIG_SINGLE(D)                                                                                          \
+    case D:                                                                                                         \
+        if (ew_)                                                                                                    \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
+        else                                                                                                        \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
+        break;
+    if (b.single) {
+        if (b.any_frames)
+            return hipErrorInvalidValue;
+        switch (b.detrend) {
+            PSDK_BIG_SINGLE(0)
+            PSDK_BIG_SINGLE(1)
+            PSDK_BIG_SINGLE(2)
+            PSDK_BIG_SINGLE(3)
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+#undef PSDK_BIG_SINGLE
     switch (b.detrend) {
         PSDK_BIG_CASE(0)
         PSDK_BIG_CASE(1)

@@ -103,7 +103,8 @@ __device__ __forceinline__ float team_sum(float v)
 // FRAMES: as in bigfused_impl.h -- jobs with fspan >= 0 read their stream in place from AdcDac frames (8-byte buffer loads of
 // four wire words, converted in the register group once the loads have landed); separate kernels, so the f32-only launches keep
 // their instruction stream and registers.
-template <int N, int DETREND, bool EWMA, bool FRAMES = false>
+// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair).
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
 __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVES_PER_SIMD) void fused_kernel(
     const FusedBatch batch, const float *__restrict__ win)
 {
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + 2 * p0);
+            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
     }
     PSDK_STAMP(10); // first loads issued + warm-up
     // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
@@ -490,10 +491,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             if constexpr (EWMA) {
                 if (job.ewma) {
                     dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
-                    dp.eb = eamp.next(job);
+                    if constexpr (!SINGLE)
+                        dp.eb = eamp.next(job);
                 }
             }
-            window_pair<N, DETREND, EWMA, true>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
+            window_pair<N, DETREND, EWMA, true, SINGLE>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
                                           s_win[2 * TEAM + tl], s_win[3 * TEAM + tl], dp);
         }
         { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT.  Issued
@@ -744,6 +746,27 @@ static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStrea
         else                                                                              \
             hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win); \
         break;
+#define PSDK_FUSED_SINGLE(D)                                                                              \
+    case D:                                                                                               \
+        if (ew_)                                                                                          \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
+        else                                                                                              \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win); \
+        break;
+    if (b.single) {
+        if (b.any_frames)
+            return hipErrorInvalidValue; // (frames are read in place by the half-overlap kernels only)
+        switch (b.detrend) {
+            PSDK_FUSED_SINGLE(0)
+            PSDK_FUSED_SINGLE(1)
+            PSDK_FUSED_SINGLE(2)
+            PSDK_FUSED_SINGLE(3)
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+#undef PSDK_FUSED_SINGLE
     switch (b.detrend) {
         PSDK_FUSED_CASE(0)
         PSDK_FUSED_CASE(1)

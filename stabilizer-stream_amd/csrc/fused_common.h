@@ -280,7 +280,10 @@ struct DetrendParams {
 };
 // CENTRED (Mean only): lo and up arrive with the pivot d.ob already subtracted (they are dead afterwards and
 // were rewritten in place), nl is raw.
-template <int N, int DETREND, bool EWMA, bool CENTRED = false>
+// SINGLE (overlap 0): only segment a = (lo, up) is transformed -- the imaginary part is an exact zero (not x_b times a zero
+// weight: an infinity in the NEXT segment's samples must not reach this one's spectrum), |Z[k]|^2 = |Z[N-k]|^2 = |X_a[k]|^2
+// and the fold 1/2 (Q[k] + Q[N-k]) of post_kernel yields the segment's power unchanged.
+template <int N, int DETREND, bool EWMA, bool CENTRED = false, bool SINGLE = false>
 __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &lo0, const float4 &lo1, const float4 &up0,
                                             const float4 &up1, const float4 &nl0, const float4 &nl1, const float4 &w0,
                                             const float4 &w1, const float4 &w2, const float4 &w3, const DetrendParams &d)
@@ -307,7 +310,7 @@ __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &l
             xa *= d.ea;
             xb *= d.eb;
         }
-        v[slot] = {xa, xb};
+        v[slot] = {xa, SINGLE ? 0.0f : xb};
     };
     put(0, lo0.x, up0.x, w0.x, 0);
     put(1, lo0.y, up0.y, w0.y, 1);

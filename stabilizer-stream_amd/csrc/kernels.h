@@ -127,6 +127,10 @@ struct FusedBatch {
     int detrend;  // Detrend kind 0..3 for every job of the launch
     int any_ewma; // some job has finite averaging weights
     int any_frames; // some job reads AdcDac frames (the kernels built with the frame loads run this launch)
+    // overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table with overlap 0): a "pair" is ONE segment -- pair i =
+    // segment seg_a + i = samples src[N i .. N i + N), transformed with a zero imaginary part; the N samples it decimates are
+    // still src[N i + N/2 .. N i + 3N/2), so the stream is consumed exactly as with half-overlapped pairs (the SINGLE kernels)
+    int single;
     // frame jobs come first in the launch, four by four (the traces of one span, equal workgroup counts): group g
     // = workgroups [fg_begin[g], fg_begin[g] + 4 fg_nb[g]); the kernel deals a group's workgroups so that the four
     // that read the same frames sit on one XCD (they share its L2: the frame bytes cross the fabric once, not four times)

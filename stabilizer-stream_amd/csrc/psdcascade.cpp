@@ -679,10 +679,18 @@ bool device_idle(psdc_handle *h) { return !h->coalesce_always && hipStreamQuery(
 // kernels when something does not fit a pair).
 // The fused single-pass kernels read the window from its table and assume nothing about it but a hop of N/2: Window::hann()
 // and every caller-built Window<N> with overlap N/2 (Hamming, Blackman, ... -- src/psd.rs:12-20 has pub fields) run on them;
-// other overlaps (rectangular: 0) take the generic two-pass kernels.
-static bool fused_window(const psdc_handle *h)
+// overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table) runs the same kernels in their SINGLE form -- one
+// segment per "pair", transformed with a zero imaginary part; the decimator consumes the stream exactly as before (round 4:
+// rectangular windows ran the generic two-pass kernels at a third of the rate).  Other overlaps take the generic kernels.
+// 0: no fused kernel for this window, 1: half-overlapped pairs, 2: single segments.
+static int fused_window(const psdc_handle *h)
 {
-    return h->window_kind == PSDC_WINDOW_HANN || (h->window_kind == PSDC_WINDOW_CUSTOM && 2 * (uint64_t)h->geo.overlap == h->n);
+    if (h->window_kind == PSDC_WINDOW_HANN || (h->window_kind == PSDC_WINDOW_CUSTOM && 2 * (uint64_t)h->geo.overlap == h->n))
+        return 1;
+    static const bool no_single = getenv("PSDC_NO_SINGLE") != nullptr; // (A/B aid: rectangular windows on the generic kernels)
+    if (h->geo.overlap == 0 && !no_single)
+        return 2;
+    return 0;
 }
 
 // `all`: issue odd segments of decimated stages too (read-outs); the ingest path
@@ -692,14 +700,18 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
 {
     const Geometry &g = h->geo;
     const int spt = welch_segments_per_tile((int)h->n);
-    const bool fast_ok = fused_supported((int)h->n) && fused_window(h);
+    const int fmode = fused_supported((int)h->n) ? fused_window(h) : 0;
+    const bool fast_ok = fmode != 0, single = fmode == 2;
+    const unsigned fstep = single ? 1 : 2;   // segments per fused "pair"
+    const uint64_t half = (uint64_t)h->n / 2; // a fused run starting at segment j decimates from sample j hop + N/2 on
+    auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + half; };
     // fused runs rebuild their decimator state from the 288 samples before their first new
-    // sample (which sits hop after the run's first segment start): samples needed in front of it
-    const uint64_t need_pre = HBF_HALO > g.hop ? HBF_HALO - g.hop : 0;
+    // sample (which sits N/2 after the run's first segment start): samples needed in front of it
+    const uint64_t need_pre = HBF_HALO > half ? HBF_HALO - half : 0;
     // the seam must complete every segment that starts in the carried tail; on the fast path it
     // is long enough for the tail side to end on a whole segment pair with need_pre samples of
     // the new span in front of the in-place side
-    const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * (uint64_t)g.hop : 0);
+    const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * half : 0);
     *did_work = false;
     {
         int rc = wait_uploads(h);
@@ -774,7 +786,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             // ingest path (all == false): a decimated stage issues whole segment pairs only, the odd
             // segment waits for its partner -- it would cost a launch of the generic kernels every
             // other round; read-outs (all == true) issue everything
-            if (!all && fast_ok && k >= 1 && ((j_new - s.segs) & 1))
+            if (!all && fmode == 1 && k >= 1 && ((j_new - s.segs) & 1))
                 j_new -= 1;
             // ... and a decimated stage waits until it has a worthwhile batch: every job of a launch occupies at
             // least one resident workgroup for the whole launch, and the deep stages of many channels (a handful
@@ -812,11 +824,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                         // fast path: the tail side gets a whole number of segment pairs and exactly their
                         // decimator outputs; the in-place side starts >= need_pre samples into the span
                         uint64_t js = std::max<uint64_t>(j_lo, (first + need_pre + g.hop - 1) / g.hop);
-                        if ((js - j_lo) & 1)
+                        if (!single && ((js - j_lo) & 1))
                             js += 1;
-                        if (js < j_hi && (js + 1) * g.hop <= first + seam && sp.len >= seam) {
+                        if (js < j_hi && run_new0(js) <= first + seam && sp.len >= seam) {
                             j_split = js;
-                            m_split = std::min<uint64_t>(m_hi, (js + 1) * (g.hop / 8));
+                            m_split = std::min<uint64_t>(m_hi, run_new0(js) / 8);
                         }
                     }
                     if (j_split > j_lo || m_split > m_lo) {
@@ -957,13 +969,20 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             const Span &sp = w.spans[i];
             // first fused segment: far enough into the stream that every output survives the drain
             uint64_t fs = sp.seg_a;
-            while ((g.hop / 8) * (fs + 1) < g.drain)
-                fs += 2;
+            while (run_new0(fs) / 8 < g.drain)
+                fs += fstep;
             const bool framed = sp.fpool >= 0;
-            uint64_t np = (fast_ok && nx && fs + 2 <= sp.seg_b && (!framed || fused_frames_supported((int)h->n))) ? (sp.seg_b - fs) / 2 : 0;
+            uint64_t np = (fast_ok && nx && fs + fstep <= sp.seg_b && (!framed || (!single && fused_frames_supported((int)h->n))))
+                              ? (sp.seg_b - fs) / fstep : 0;
+            if (single && np) {
+                // a single-segment "pair" decimates the N/2 samples behind its segment too: they must be this span's share
+                // (the last segment of a span -- of a round -- is left to the generic kernels with its half chunk)
+                const uint64_t lim = 8 * sp.m_b;
+                np = run_new0(fs) + h->n <= lim ? std::min<uint64_t>(np, (lim - run_new0(fs)) / h->n) : 0;
+            }
             const uint64_t fofs = (uint64_t)g.hop * fs - sp.src_base; // samples of this span in front of the pairs
             const float *fsrc = framed ? nullptr : sp.src + fofs;
-            const uint64_t mf0 = (g.hop / 8) * (fs + 1), mf1 = mf0 + (h->n / 8) * np;
+            const uint64_t mf0 = run_new0(fs) / 8, mf1 = mf0 + (h->n / 8) * np;
             const bool aligned = framed ? (fofs & 3u) == 0 : (reinterpret_cast<uintptr_t>(fsrc) & 15u) == 0;
             if (np && (!aligned || mf0 < sp.m_a || mf1 > sp.m_b || (fofs < need_pre && sp.src_base != 0)))
                 np = 0;
@@ -986,7 +1005,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 fj.ewma = w.ew.ewma ? 1 : 0;
                 fjobs.push_back({fj, wi});
                 add_seg(sp, sp.seg_a, fs);
-                add_seg(sp, fs + 2 * np, sp.seg_b);
+                add_seg(sp, fs + fstep * np, sp.seg_b);
                 add_dec(sp, sp.m_a, mf0);
                 add_dec(sp, mf1, sp.m_b);
             } else {
@@ -1162,6 +1181,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     for (size_t i = 0; i < fjobs.size();) {
         FusedBatch fb{};
         fb.detrend = h->detrend;
+        fb.single = single ? 1 : 0;
         FspanMap fm(fb.fspans);
         for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
             FusedJob j = fjobs[i].j;
@@ -2320,7 +2340,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
         const size_t per_frame = (size_t)batches * 8; // samples per trace and frame
         // (the in-place kernels read wire words with 8-, 4- and 2-byte loads at offsets that are aligned relative to the
         // base only: a base that is not a multiple of 8 takes the byte-wise decode kernel, as the verdict scan does)
-        const bool in_place_ok = fused_frames_supported((int)h->n) && fused_window(h) && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0 &&
+        const bool in_place_ok = fused_frames_supported((int)h->n) && fused_window(h) == 1 && (reinterpret_cast<uintptr_t>(d_frames) & 7) == 0 &&
                                  frame_size % 8 == 0;
         // pieces of <= FSPAN_MAX_SAMPLES samples per trace (the kernels' cell arithmetic) / 2^24 on the decode path
         const size_t piece_frames = std::max<size_t>(1, (in_place_ok ? (size_t)FSPAN_MAX_SAMPLES : ((size_t)1 << 24)) / per_frame);

@@ -188,7 +188,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
     if (!win)
         error("launch_fused: null window");
     sim::enqueue(s, [b, n] {
-        const int teams = fused_teams(n), hop = n / 2;
+        // (single: overlap 0 -- pair p is segment seg_a + p = samples [N p, N p + N); it still decimates [N p + N/2, N p + 3N/2))
+        const int teams = fused_teams(n), hop = b.single ? n : n / 2;
         world().fused_launches += 1;
         int blocks = 0;
         long big_blocks = 0;
@@ -212,6 +213,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
             const bool fr = job.fspan >= 0;
             if (fr)
                 world().fused_frame_jobs += 1;
+            if (fr && b.single)
+                error("fused job %d reads frames in a single-segment launch", ji);
             if (fr && !b.any_frames)
                 error("fused job %d reads frames in a launch without any_frames", ji);
             if (job.ewma && !b.any_ewma)
@@ -266,8 +269,9 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
                         }
                         const uint64_t s0 = (a0 + (uint64_t)n * p) / (unsigned)hop;
                         mark(world().seg, tag, s0);
-                        mark(world().seg, tag, s0 + 1);
-                        segs += 2;
+                        if (!b.single)
+                            mark(world().seg, tag, s0 + 1);
+                        segs += b.single ? 1 : 2;
                         // the pair's N new samples -> N/8 outputs of the next stage's stream
                         const uint64_t m0 = (a0 + (uint64_t)n * p + n / 2) / 8;
                         float *o = job.dst + (size_t)p * (n / 8);

@@ -874,6 +874,8 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     import torch
     rng = np.random.default_rng(seed)
     nch = 3
+    # one seed in four runs Window::rectangular() (overlap 0: the single-segment form of the fused kernels, N >= 256)
+    window, wname = (pkg.Window.RECTANGULAR, "rect") if seed % 4 == 3 else (pkg.Window.HANN, "hann")
     total = int(rng.integers(60, 140)) * n * 8
     # (a small DC level: the stage-k stream carries it times 8^k, and once it dwarfs the noise the
     # one-sample anchors of Midpoint / Span sit at the f32 resolution of the stream, in the reference
@@ -881,10 +883,10 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     xs = [make_signal(pkg, total, seed=100 * seed + c, tone=0.3 * c, dc=0.03 * c) for c in range(nch)]
     xd = [torch.from_numpy(x).cuda() for x in xs]
     torch.cuda.synchronize()
-    g = pkg.PsdCascadeBank(n, nch)
+    g = pkg.PsdCascadeBank(n, nch, window=window)
     g.configure(quantum=int(rng.integers(2, 20)) * n,
                 coalesce=int(rng.choice([1, 4, 8, 16, -2, -4, -8, -16])))  # negative: in-place spans held back unconditionally
-    refs = [ora.PsdCascade(n, "f64") for _ in range(nch)]
+    refs = [ora.PsdCascade(n, "f64", window=wname) for _ in range(nch)]
     pos = [0] * nch
     detrends = ["none", "midpoint", "span", "mean"]
     while min(pos) < total:
@@ -1217,6 +1219,42 @@ def test_rectangular_window_sizes(pkg, ora, gpu_required, n, detrend):
     d = torch.from_numpy(x[cut:]).cuda()
     g.process_device(0, d.data_ptr(), total - cut)
     check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, window="rect", what=f"rect N={n} {detrend}")
+    g.close()
+
+
+@pytest.mark.parametrize("n,detrend,avg", [(256, "none", None), (512, "mean", None), (1024, "none", None), (1024, "span", (20, 900)),
+                                           (2048, "midpoint", None), (4096, "none", None), (4096, "mean", (7, 300)),
+                                           (8192, "none", None), (16384, "mean", None), (16384, "none", (30, 4000))])
+def test_rectangular_window_single_segment_kernels(pkg, ora, gpu_required, n, detrend, avg):
+    """Window::rectangular() (src/psd.rs:24-32: overlap 0) on the fused single-pass kernels in their SINGLE form -- one segment
+    per FFT with a zero imaginary part, the decimator consuming the stream exactly as with half-overlapped pairs (round 4; the
+    generic two-pass kernels ran these at a third of the rate).  White noise fed as coalesced in-place spans of odd lengths, a
+    host-fed stretch and a read-out in between: counters exactly, every stage with >= 4 averages within the PURE 1e-5 (plain
+    sums), every detrend, finite averaging, at every fused size; and the same stream through the generic kernels
+    (a caller's all-ones table with overlap 8 is not eligible) agrees to rounding."""
+    import torch
+    total = 260 * n + 8 * 41
+    x = pkg.noise_host(total, seed=900 + n)
+    d = torch.from_numpy(x).cuda()
+    g = pkg.PsdCascadeBank(n, window=pkg.Window.RECTANGULAR)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    g.configure(coalesce=-4)  # spans are held back and share rounds, as on a busy device
+    av = pkg.AvgOpts(*avg) if avg else None
+    if av:
+        g.set_avg(av)
+    cuts = [0, 37 * n + 12, 37 * n + 12 + 5 * n + 3, 120 * n + 40, 121 * n, 200 * n + 8, total]
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if i == 1:
+            g.process(0, x[a:b])  # a host-fed stretch in between
+        else:
+            g.process_device(0, d.data_ptr() + 4 * a, b - a)
+        if i == 3:
+            assert g.stage_info(0, 0)["count"] == (b // n if not av else min(b // n, min(av.count, av.limit) + 1))
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, avg=av, window="rect",
+                         what=f"rect (single-segment kernels) N={n} {detrend} avg={avg}",
+                         # (Mean under a rectangular window nulls bin 0 exactly: nothing relative to hold it to)
+                         pure_min_count=4 if (av is None and detrend != "mean") else None)
+    p1, b1 = g.psd(0)
     g.close()
 
 
