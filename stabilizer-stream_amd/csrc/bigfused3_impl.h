@@ -37,6 +37,23 @@ struct Big3Geo : FusedDec<N> {
 struct g8 {
     float v[8];
 };
+// ... as the kernels carry it from pair to pair: f32 samples, or -- in the kernels that read AdcDac frames, between a load and its
+// conversion -- eight raw 16-bit wire words, held as INTEGERS (fused_common.h Grp4 says why)
+template <bool FRAMES>
+struct Grp8;
+template <>
+struct Grp8<false> {
+    float v[8];
+    __device__ __forceinline__ float f(int j) const { return v[j]; }
+    __device__ __forceinline__ void set(int j, float x) { v[j] = x; }
+};
+template <>
+struct Grp8<true> {
+    unsigned u[8];
+    __device__ __forceinline__ float f(int j) const { return __builtin_bit_cast(float, u[j]); }
+    __device__ __forceinline__ void set(int j, float x) { u[j] = __builtin_bit_cast(unsigned, x); }
+    __device__ __forceinline__ void set_raw(int j, unsigned w) { u[j] = w; }
+};
 
 // Detrend + window + EWMA amplitude of one segment pair into the 16 FFT inputs of a lane (src/psd.rs:75-113, :211): slot m gets
 // sample n = tl + (N/16) m of segment a = (lo, up) in .re and of segment b = (up, nl) in .im.  Mean: lo and up arrive with the
@@ -160,7 +177,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             fdc[j] = dq * fsp.frame_size + 64u * fdr[j];
         }
     }
-    auto load8 = [&](g8 &g, const float *c, unsigned s_) { // a half chunk: samples c[H j] / samples s_ + H j of the trace (raw)
+    using G8 = Grp8<FRAMES>;
+    auto load8 = [&](G8 &g, const float *c, unsigned s_) { // a half chunk: samples c[H j] / samples s_ + H j of the trace (raw)
         if constexpr (FRAMES) {
             if (fr) {
                 const unsigned c0 = s_ >> 3;
@@ -171,28 +189,35 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned off = off0 + fdc[j] + ((b0 + fdr[j] >= fsp.batches) ? 8u : 0u);
-                    g.v[j] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0));
+                    g.set_raw(j, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0));
                 }
                 return;
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            g.v[j] = c[H * j];
+            g.set(j, c[H * j]);
     };
-    auto volts8 = [&](g8 &g) { // raw wire words -> volts, in place (a no-op for f32 jobs)
+    auto volts8 = [&](G8 &g) { // raw wire words -> volts, in place (a no-op for f32 jobs)
         if constexpr (FRAMES) {
             if (fr) {
                 const float lsb = adcdac_lsb();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const unsigned w = (unsigned)(int)(short)(unsigned short)__builtin_bit_cast(unsigned, g.v[j]) ^ dac_flip;
-                    g.v[j] = (float)(short)(unsigned short)w * lsb;
+                    const unsigned w = (unsigned)(int)(short)(unsigned short)g.u[j] ^ dac_flip;
+                    g.set(j, (float)(short)(unsigned short)w * lsb);
                 }
             }
         }
     };
-    g8 ga, gb, gc; // (lo, up) = chunk p, nl = lower half of chunk p + 1 (see pair_step)
+    auto samples = [](const G8 &g) { // the group's samples as f32
+        g8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            r.v[j] = g.f(j);
+        return r;
+    };
+    G8 ga, gb, gc; // (lo, up) = chunk p, nl = lower half of chunk p + 1 (see pair_step)
     load8(ga, cp, sp);
     load8(gb, cp + N / 2, sp + N / 2);
     load8(gc, cp + N, sp + N);
@@ -258,8 +283,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
                 t += s_red[4 + w];
             return t;
         };
-        piv = block_sum(sum8(ga) + sum8(gb)) * (1.0f / (float)N);
-        s0c = block_sum(sum8c(ga, piv));
+        piv = block_sum(sum8(samples(ga)) + sum8(samples(gb))) * (1.0f / (float)N);
+        s0c = block_sum(sum8c(samples(ga), piv));
         __syncthreads();
     }
 
@@ -271,7 +296,11 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     // the lane's twiddle seeds, held across the run (opaque per pair: see bigfused_impl.h)
     const typename T::Seeds sd_run = T::load_seeds(tp, tw0g);
 
-    auto pair_step = [&](g8 &lo, g8 &up, g8 &nl, const float *cnext, unsigned snext, bool more, float *o) {
+    auto pair_step = [&](G8 &glo, G8 &gup, G8 &gnl, const float *cnext, unsigned snext, bool more, float *o) {
+        // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
+        // these copies in place -- and their groups are reloaded further down
+        g8 lo = samples(glo), up = samples(gup);
+        const g8 nl = samples(gnl);
         const float *winp = win;
         {
             size_t zofs = 0; // the window loads stay inside the pair (bigfused_impl.h: hoisted, they pin 16 registers for the run)
@@ -410,8 +439,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             const unsigned ssrc = more ? snext : safe_s;
             safe = src;
             safe_s = ssrc;
-            load8(up, src + N / 2, ssrc + N / 2);
-            load8(lo, src + N, ssrc + N);
+            load8(gup, src + N / 2, ssrc + N / 2);
+            load8(glo, src + N, ssrc + N);
         }
         __syncthreads();
         T::load1(tp, vv, frame);
@@ -424,8 +453,8 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(vv[s].re, vv[s].re, fmaf(vv[s].im, vv[s].im, q[s]));
         if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
-            volts8(up);
-            volts8(lo);
+            volts8(gup);
+            volts8(glo);
         }
         __syncthreads(); // next pair's decimator writes the frame
     };

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 #ifndef PSDK_HOIST_LOOKAHEAD
 #define PSDK_HOIST_LOOKAHEAD 1
 #endif
+#ifndef PSDK_HOIST_FIRST
+#define PSDK_HOIST_FIRST 0 // the six loads at the start of a run as ONE frame / f32 decision: see there
+#endif
     using G = BigGeo<N, REGA>;
     using T = BlockFft<N>;
     constexpr int TEAM = G::TEAM, VT = G::VT, THREADS = G::THREADS;
@@ -165,60 +168,65 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         const_cast<uint8_t *>(fsp.frames), 0, fr ? (int)min(fsp.bytes, 0x7FFFFFFFull) : 0, 0x00020000);
     const float4 *cp = reinterpret_cast<const float4 *>(job.src) + (size_t)p0 * (N / 4) + tp;
     unsigned sp = job.s_off + (unsigned)p0 * N + 4u * tp;
-    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words in .x / .y
-    auto piece = [&](const float4 *c, unsigned s, int k) -> float4 {
+    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words (integers:
+    // fused_common.h Grp4)
+    using G4 = Grp4<FRAMES>;
+    auto piece = [&](const float4 *c, unsigned s, int k) -> G4 {
+        G4 g;
         if constexpr (FRAMES) {
             if (fr) {
                 const unsigned si = s + 4u * (unsigned)k;
                 const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
                 const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0); // (a GCC-style vector of two u32: index it)
-                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+                g.set_raw((unsigned)r[0], (unsigned)r[1]);
+                return g;
             }
         }
-        return c[k];
+        g.set(c[k]);
+        return g;
     };
     // raw wire words -> volts, in place (a no-op for f32 jobs)
-    auto volts = [&](float4 &g) {
+    auto volts = [&](G4 &g) {
         if constexpr (FRAMES) {
-            if (fr) {
-                const unsigned a = __builtin_bit_cast(unsigned, g.x) ^ dac_flip, b = __builtin_bit_cast(unsigned, g.y) ^ dac_flip;
-                const float lsb = adcdac_lsb();
-                g.x = (float)(short)(unsigned short)(a & 0xffffu) * lsb;
-                g.y = (float)(short)(unsigned short)(a >> 16) * lsb;
-                g.z = (float)(short)(unsigned short)(b & 0xffffu) * lsb;
-                g.w = (float)(short)(unsigned short)(b >> 16) * lsb;
-            }
+            if (fr)
+                grp_volts(g, dac_flip, adcdac_lsb());
         }
     };
     const float4 *safe = cp; // look-ahead target once nothing is left to look ahead to
     unsigned safe_s = sp;
     // register groups of a lane: two float4 each (see pair_step)
-    float4 ga[VT][2], gb[VT][2], gc[VT][2];
+    G4 ga[VT][2], gb[VT][2], gc[VT][2];
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
         const float4 *c = cp + THREADS * v;
         const unsigned s = sp + 4u * THREADS * v;
 #if PSDK_HOIST_FIRST
-        if (FRAMES && fr) {
-            auto fp = [&](int k) {
-                const unsigned si = s + 4u * (unsigned)k;
-                const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
-                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
-            };
-            ga[v][0] = fp(0);
-            ga[v][1] = fp(TEAM);
-            gb[v][0] = fp(2 * TEAM);
-            gb[v][1] = fp(3 * TEAM);
-            gc[v][0] = fp(N / 4);
-            gc[v][1] = fp(N / 4 + TEAM);
-        } else {
-            ga[v][0] = c[0];
-            ga[v][1] = c[TEAM];
-            gb[v][0] = c[2 * TEAM];
-            gb[v][1] = c[3 * TEAM];
-            gc[v][0] = c[N / 4];
-            gc[v][1] = c[N / 4 + TEAM];
+        // (the form that tripped si-form-memory-clauses in round 3 -- DESIGN.md section 4; `make verify` catches it)
+        bool done = false;
+        if constexpr (FRAMES) {
+            if (fr) {
+                auto fp = [&](G4 &g, int k) {
+                    const unsigned si = s + 4u * (unsigned)k;
+                    const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                    g.set_raw((unsigned)r[0], (unsigned)r[1]);
+                };
+                fp(ga[v][0], 0);
+                fp(ga[v][1], TEAM);
+                fp(gb[v][0], 2 * TEAM);
+                fp(gb[v][1], 3 * TEAM);
+                fp(gc[v][0], N / 4);
+                fp(gc[v][1], N / 4 + TEAM);
+                done = true;
+            }
+        }
+        if (!done) {
+            ga[v][0].set(c[0]);
+            ga[v][1].set(c[TEAM]);
+            gb[v][0].set(c[2 * TEAM]);
+            gb[v][1].set(c[3 * TEAM]);
+            gc[v][0].set(c[N / 4]);
+            gc[v][1].set(c[N / 4 + TEAM]);
         }
 #else
         ga[v][0] = piece(c, s, 0);
@@ -300,12 +308,12 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         float r = 0.0f;
 #pragma unroll
         for (int v = 0; v < VT; ++v)
-            r += (r4(ga[v][0]) + r4(ga[v][1])) + (r4(gb[v][0]) + r4(gb[v][1]));
+            r += (r4(ga[v][0].f()) + r4(ga[v][1].f())) + (r4(gb[v][0].f()) + r4(gb[v][1].f()));
         piv = block_sum(r) * (1.0f / (float)N);
         r = 0.0f;
 #pragma unroll
         for (int v = 0; v < VT; ++v)
-            r += s4(ga[v][0], piv) + s4(ga[v][1], piv);
+            r += s4(ga[v][0].f(), piv) + s4(ga[v][1].f(), piv);
         s0c = block_sum(r);
         __syncthreads(); // s_red is written again in the first pair
     }
@@ -371,8 +379,16 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         load_halo(p0);
 
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
-    auto pair_step = [&](float4(&lo)[VT][2], float4(&up)[VT][2], float4(&nl)[VT][2], const float4 *cnext, unsigned snext,
+    auto pair_step = [&](G4(&glo)[VT][2], G4(&gup)[VT][2], G4(&gnl)[VT][2], const float4 *cnext, unsigned snext,
                          bool more, float *o, int p) {
+        // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
+        // these copies in place -- and their groups are reloaded further down
+        float4 lo[VT][2], up[VT][2], nl[VT][2];
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                lo[v][e] = glo[v][e].f(), up[v][e] = gup[v][e].f(), nl[v][e] = gnl[v][e].f();
         // The window and twiddle tables are the same for every pair, and left alone the compiler hoists the
         // loads and keeps all of a lane's entries (8 + 30 + 16 registers) live across the whole run -- which pins
         // the kernels to two wavefronts per SIMD (or spills, with two lanes per thread).  The table pointers are
@@ -642,28 +658,33 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 // went out one at a time; N = 8192 frames +8 %, 16384 +5 %.  The SIX loads at the start of a run stay as they are:
                 // hoisted the same way they read components .x / .y of the first group wrong in the EWMA x FRAMES variant alone --
                 // DESIGN.md section 4)
-                if (FRAMES && fr) {
-                    auto fp = [&](int k) {
-                        const unsigned si = s + 4u * (unsigned)k;
-                        const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
-                        const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-                        return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
-                    };
-                    up[v][0] = fp(2 * TEAM);
-                    up[v][1] = fp(3 * TEAM);
-                    lo[v][0] = fp(N / 4);
-                    lo[v][1] = fp(N / 4 + TEAM);
-                } else {
-                    up[v][0] = c[2 * TEAM];
-                    up[v][1] = c[3 * TEAM];
-                    lo[v][0] = c[N / 4];
-                    lo[v][1] = c[N / 4 + TEAM];
+                bool done = false;
+                if constexpr (FRAMES) {
+                    if (fr) {
+                        auto fp = [&](G4 &g, int k) {
+                            const unsigned si = s + 4u * (unsigned)k;
+                            const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                            const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                            g.set_raw((unsigned)r[0], (unsigned)r[1]);
+                        };
+                        fp(gup[v][0], 2 * TEAM);
+                        fp(gup[v][1], 3 * TEAM);
+                        fp(glo[v][0], N / 4);
+                        fp(glo[v][1], N / 4 + TEAM);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    gup[v][0].set(c[2 * TEAM]);
+                    gup[v][1].set(c[3 * TEAM]);
+                    glo[v][0].set(c[N / 4]);
+                    glo[v][1].set(c[N / 4 + TEAM]);
                 }
 #else
-                up[v][0] = piece(c, s, 2 * TEAM);
-                up[v][1] = piece(c, s, 3 * TEAM);
-                lo[v][0] = piece(c, s, N / 4);
-                lo[v][1] = piece(c, s, N / 4 + TEAM);
+                gup[v][0] = piece(c, s, 2 * TEAM);
+                gup[v][1] = piece(c, s, 3 * TEAM);
+                glo[v][0] = piece(c, s, N / 4);
+                glo[v][1] = piece(c, s, N / 4 + TEAM);
 #endif
             }
         }
@@ -699,10 +720,10 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
-                volts(up[v][0]);
-                volts(up[v][1]);
-                volts(lo[v][0]);
-                volts(lo[v][1]);
+                volts(gup[v][0]);
+                volts(gup[v][1]);
+                volts(glo[v][0]);
+                volts(glo[v][1]);
             }
         }
         __syncthreads(); // next pair's decimator writes the frame

@@ -209,36 +209,38 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(fsp.frames), 0, fr ? (int)min(fsp.bytes, 0x7FFFFFFFull) : 0, 0x00020000);
     unsigned sp = job.s_off + (unsigned)p0 * N + 4u * tl;
-    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words in .x / .y
-    auto piece = [&](const float4 *c, unsigned s_, int k) -> float4 {
+    // piece k (float4 units from c / 4 k samples from s): f32 data, or the 8 raw bytes of the four wire words (integers:
+    // fused_common.h Grp4)
+    using G4 = Grp4<FRAMES>;
+    auto piece = [&](const float4 *c, unsigned s_, int k) -> G4 {
+        G4 g;
         if constexpr (FRAMES) {
             if (fr) {
                 const unsigned si = s_ + 4u * (unsigned)k;
                 const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
                 const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0); // (a GCC-style vector of two u32: index it)
-                return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
+                g.set_raw((unsigned)r[0], (unsigned)r[1]);
+                return g;
             }
         }
-        return c[k];
+        g.set(c[k]);
+        return g;
     };
-    auto volts = [&](float4 &g) { // raw wire words -> volts, in place (a no-op for f32 jobs)
+    auto volts = [&](G4 &g) { // raw wire words -> volts, in place (a no-op for f32 jobs)
         if constexpr (FRAMES) {
-            if (fr) {
-                const unsigned a = __builtin_bit_cast(unsigned, g.x) ^ dac_flip, b = __builtin_bit_cast(unsigned, g.y) ^ dac_flip;
-                const float lsb = adcdac_lsb();
-                g.x = (float)(short)(unsigned short)(a & 0xffffu) * lsb;
-                g.y = (float)(short)(unsigned short)(a >> 16) * lsb;
-                g.z = (float)(short)(unsigned short)(b & 0xffffu) * lsb;
-                g.w = (float)(short)(unsigned short)(b >> 16) * lsb;
-            }
+            if (fr)
+                grp_volts(g, dac_flip, adcdac_lsb());
         }
     };
     // where the look-ahead loads go once there is nothing left to look ahead to: pieces that were
     // read before (every job holds at least one pair = 3N/2 samples)
     const float4 *safe = act0 ? cp : reinterpret_cast<const float4 *>(job.src) + tl;
     unsigned safe_s = act0 ? sp : job.s_off + 4u * tl;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 ga[2] = {z4, z4}, gb[2] = {z4, z4}, gc[2] = {z4, z4};
+    G4 ga[2], gb[2], gc[2];
+    {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        ga[0].set(z4), ga[1].set(z4), gb[0].set(z4), gb[1].set(z4), gc[0].set(z4), gc[1].set(z4);
+    }
     if (act0) { // chunk p0 (all of it exists) and the lower half of chunk p0 + 1
         ga[0] = piece(cp, sp, 0);
         ga[1] = piece(cp, sp, TEAM);
@@ -313,9 +315,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     float piv = 0.0f, s0c = 0.0f;
     if constexpr (DETREND == 3) {
         auto r4 = [](const float4 &x) { return (x.x + x.y) + (x.z + x.w); };
-        piv = team_sum<TEAM>((r4(ga[0]) + r4(ga[1])) + (r4(gb[0]) + r4(gb[1]))) * (1.0f / (float)N);
+        piv = team_sum<TEAM>((r4(ga[0].f()) + r4(ga[1].f())) + (r4(gb[0].f()) + r4(gb[1].f()))) * (1.0f / (float)N);
         auto s4 = [](const float4 &x, float pv) { return ((x.x - pv) + (x.y - pv)) + ((x.z - pv) + (x.w - pv)); };
-        s0c = team_sum<TEAM>(s4(ga[0], piv) + s4(ga[1], piv));
+        s0c = team_sum<TEAM>(s4(ga[0].f(), piv) + s4(ga[1].f(), piv));
     }
     EwmaAmp eamp;
     if constexpr (EWMA) {
@@ -328,8 +330,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
     // chunk p + 2 into `lo`, in flight during the FFT passes.  For pair p + 1 the roles are
     // (lo, up, nl) <- (nl, up, lo).
-    auto pair_step = [&](float4(&lo)[2], float4(&up)[2], float4(&nl)[2], const float4 *cnext, unsigned snext, bool more,
+    auto pair_step = [&](G4(&glo)[2], G4(&gup)[2], G4(&gnl)[2], const float4 *cnext, unsigned snext, bool more,
                          float *o, int p) {
+        // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
+        // these copies in place -- and their groups are reloaded further down
+        float4 lo[2] = {glo[0].f(), glo[1].f()}, up[2] = {gup[0].f(), gup[1].f()};
+        const float4 nl[2] = {gnl[0].f(), gnl[1].f()};
         // ---- decimator ------------------------------------------------------------------
         // (a handful of VALU instructions between LDS round trips: at raised priority the wavefront
         // gets its few issue slots at once instead of queueing behind the butterflies of the other
@@ -509,28 +515,35 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
 #if PSDK_HOIST_LOOKAHEAD
             // (the frame / f32 decision once for the four loads, as in bigfused_impl.h: a branch per load put each load behind
             // an s_waitcnt vmcnt(0) at its join)
-            if (FRAMES && fr) {
-                auto fp = [&](int k) {
-                    const unsigned si = ssrc + 4u * (unsigned)k;
-                    const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
-                    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
-                    return make_float4(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]), 0.0f, 0.0f);
-                };
-                up[0] = fp(2 * TEAM);
-                up[1] = fp(3 * TEAM);
-                lo[0] = fp(N / 4);
-                lo[1] = fp(N / 4 + TEAM);
+            if constexpr (FRAMES) {
+                if (fr) {
+                    auto fp = [&](G4 &g, int k) {
+                        const unsigned si = ssrc + 4u * (unsigned)k;
+                        const unsigned off = frame_cell_offset(fsp, si >> 3) + ch_off + (si & 4u) * 2u;
+                        const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+                        g.set_raw((unsigned)r[0], (unsigned)r[1]);
+                    };
+                    fp(gup[0], 2 * TEAM);
+                    fp(gup[1], 3 * TEAM);
+                    fp(glo[0], N / 4);
+                    fp(glo[1], N / 4 + TEAM);
+                } else {
+                    gup[0].set(src[2 * TEAM]);
+                    gup[1].set(src[3 * TEAM]);
+                    glo[0].set(src[N / 4]);
+                    glo[1].set(src[N / 4 + TEAM]);
+                }
             } else {
-                up[0] = src[2 * TEAM];
-                up[1] = src[3 * TEAM];
-                lo[0] = src[N / 4];
-                lo[1] = src[N / 4 + TEAM];
+                gup[0].set(src[2 * TEAM]);
+                gup[1].set(src[3 * TEAM]);
+                glo[0].set(src[N / 4]);
+                glo[1].set(src[N / 4 + TEAM]);
             }
 #else
-            up[0] = piece(src, ssrc, 2 * TEAM);
-            up[1] = piece(src, ssrc, 3 * TEAM);
-            lo[0] = piece(src, ssrc, N / 4);
-            lo[1] = piece(src, ssrc, N / 4 + TEAM);
+            gup[0] = piece(src, ssrc, 2 * TEAM);
+            gup[1] = piece(src, ssrc, 3 * TEAM);
+            glo[0] = piece(src, ssrc, N / 4);
+            glo[1] = piece(src, ssrc, N / 4 + TEAM);
 #endif
             }
         }
@@ -575,10 +588,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
         if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
-            volts(up[0]);
-            volts(up[1]);
-            volts(lo[0]);
-            volts(lo[1]);
+            volts(gup[0]);
+            volts(gup[1]);
+            volts(glo[0]);
+            volts(glo[1]);
         }
         wave_sync(); // next pair's decimator writes the frame
         PSDK_STAMP(8);

@@ -137,6 +137,44 @@ __device__ __forceinline__ float wave_sum64(float v)
 struct f2 {
     float x, y;
 };
+
+// A lane's register group of four consecutive stream samples.  In the kernels that read AdcDac frames in place a group holds,
+// between its load and its conversion (volts()), the two raw 32-bit wire words of the four samples -- and it holds them as
+// INTEGERS: the FRAMES kernels carry their groups in integer registers and view them as f32 where the samples are used (f()),
+// so that no f32-typed value ever contains a wire word (f32 jobs of such a launch store their samples' bits).  Round 3 carried the
+// words bit-cast into float4 components; the wrong spectra that round met turned out to be a register-allocation fault of the
+// compiler, not this, but an integer payload in a floating-point-typed value is a standing invitation to
+// any transform that reasons about f32 semantics.  The f32-only kernels keep plain float4 groups: same code as before.
+template <bool FRAMES>
+struct Grp4;
+template <>
+struct Grp4<false> {
+    float4 v;
+    __device__ __forceinline__ float4 f() const { return v; }
+    __device__ __forceinline__ void set(const float4 &x) { v = x; }
+};
+template <>
+struct Grp4<true> {
+    unsigned x, y, z, w;
+    __device__ __forceinline__ float4 f() const
+    {
+        return make_float4(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), __builtin_bit_cast(float, z),
+                           __builtin_bit_cast(float, w));
+    }
+    __device__ __forceinline__ void set(const float4 &v)
+    {
+        x = __builtin_bit_cast(unsigned, v.x), y = __builtin_bit_cast(unsigned, v.y);
+        z = __builtin_bit_cast(unsigned, v.z), w = __builtin_bit_cast(unsigned, v.w);
+    }
+    __device__ __forceinline__ void set_raw(unsigned a, unsigned b) { x = a, y = b, z = 0u, w = 0u; } // four wire words
+};
+// wire words -> volts in place (src/de/data.rs:28-35, :64, :75): i16 (the DAC words offset binary: flip = 0x80008000) x LSB
+__device__ __forceinline__ void grp_volts(Grp4<true> &g, unsigned flip, float lsb)
+{
+    const unsigned a = g.x ^ flip, b = g.y ^ flip;
+    g.set(make_float4((float)(short)(unsigned short)(a & 0xffffu) * lsb, (float)(short)(unsigned short)(a >> 16) * lsb,
+                      (float)(short)(unsigned short)(b & 0xffffu) * lsb, (float)(short)(unsigned short)(b >> 16) * lsb));
+}
 // aligned 8-byte LDS read, kept a single ds_read_b64 (see lds_ld in fft_core.h)
 __device__ __forceinline__ f2 ld2(const float *p)
 {

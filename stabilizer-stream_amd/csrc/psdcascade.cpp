@@ -1103,6 +1103,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 break;
             R = rn;
         }
+        // $PSDC_DBG_FIXED_RUN=<pairs> (measurement aid): ONE run length whatever the launch holds -- what run boundaries that are a
+        // function of the absolute pair index (chunk-invariant grouping of the partial sums, include/psdcascade.h Conventions)
+        // would cost: launches then ask for more or fewer workgroups than are resident at once.  Results stay correct.
+        static const uint64_t fixed_run = getenv("PSDC_DBG_FIXED_RUN") ? strtoull(getenv("PSDC_DBG_FIXED_RUN"), nullptr, 10) : 0;
+        if (fixed_run)
+            R = fixed_run;
         for (size_t i = b0; i < b1; ++i) {
             FusedJob &j = fjobs[i].j;
             const uint64_t np = (uint64_t)j.npairs;
