@@ -228,18 +228,19 @@ class FrameReplay:
     waits for that event."""
 
     def __init__(self, torch, frames_u8, frame_size, n_frames, batches):
+        assert frame_size % 4 == 0  # 8 + 64 x batches: the buffer is also an [n_frames, frame_size / 4] array of 32-bit words
         self.torch, self.fs, self.nf, self.batches = torch, frame_size, n_frames, batches
-        hdr = frames_u8.reshape(n_frames, frame_size)[:, 4:8].copy().view("<u4").reshape(n_frames).astype(np.int64)
-        self.seq = [torch.from_numpy(((hdr + k * n_frames * batches) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).cuda() for k in range(2)]
         self.buf = [torch.from_numpy(frames_u8).cuda() for _ in range(2)]
+        # word 1 of every frame is its `seq` (src/de/frame.rs:5-9): ONE strided in-place add moves a whole buffer on
+        # (int32 arithmetic wraps like the u32 on the wire)
+        self.seq = [b.view(torch.int32).view(n_frames, frame_size // 4)[:, 1] for b in self.buf]
         self.ev = [None, None]
         self.k = 0
-        self._write(1)
+        self._advance(1, n_frames * batches)
         torch.cuda.synchronize()
 
-    def _write(self, b):
-        v = self.buf[b].view(self.nf, self.fs)
-        v[:, 4:8] = self.seq[b].view(self.torch.uint8).view(self.nf, 4)
+    def _advance(self, b, by):
+        self.seq[b].add_(by)
         e = self.torch.cuda.Event()
         e.record()
         self.ev[b] = e
@@ -249,8 +250,7 @@ class FrameReplay:
         if self.ev[b] is not None:
             self.ev[b].synchronize()  # (recorded two calls ago)
         bank.process_adcdac_frames_device(self.buf[b].data_ptr(), self.fs, self.nf)
-        self.seq[b] += 2 * self.nf * self.batches  # int32 arithmetic wraps like the u32 on the wire
-        self._write(b)
+        self._advance(b, 2 * self.nf * self.batches)
         self.k += 1
 
 
