@@ -219,6 +219,25 @@ void scenario_stress(uint64_t seed)
             CK(psdc_sync(h));
             continue;
         }
+        if (kind < 0.195) { // Clone (src/psd.rs:399): the copy carries on where the original stood, the original goes
+            psdc_handle *c = psdc_clone(h);
+            if (!c) {
+                fail("psdc_clone: %s", psdc_last_error(nullptr));
+                continue;
+            }
+            psdc_destroy(h);
+            h = c;
+            continue;
+        }
+        if (kind < 0.2 && *std::max_element(pos.begin(), pos.end()) < total / 3) { // Cmd::Reset (src/bin/psd.rs:190): start over
+            CK(psdc_reset(h));
+            sim::drain();
+            const int cap = world().cap_blocks;
+            world() = sim::World{};
+            world().cap_blocks = cap;
+            std::fill(pos.begin(), pos.end(), 0);
+            continue;
+        }
         const uint64_t pick = r.u(0, 3);
         uint64_t m = pick == 0 ? r.u(1, 50) : pick == 1 ? r.u(1, 6 * (uint64_t)n) : r.u(6 * (uint64_t)n, 40 * (uint64_t)n);
         m = std::min<uint64_t>(m, total - pos[c]);
