@@ -118,7 +118,7 @@ typedef struct psdc_profile {
 /* ---- lifecycle ----------------------------------------------------------- */
 
 /* PsdCascade::<N>::default() (src/psd.rs:408-423) for `n_channels` traces on HIP
- * device `device`.  n: a power of two 16 ... 16384, or ANY size 16 < n <= 8192 (the reference takes any
+ * device `device`.  n: a power of two 16 ... 131072, or ANY size 16 < n <= 8192 (the reference takes any
  * N >= 2 with (N - overlap) % 8 == 0, src/psd.rs:138,247 -- rustfft plans any length, :418; with the Hann
  * window's overlap N/2 that is every multiple of 16).  Returns NULL on failure; psdc_last_error(NULL)
  * explains.
@@ -361,7 +361,7 @@ int psdc_stitch_window(uint32_t n, float power, float nenbw, size_t overlap, uin
  * process) collects them -- and the receiver stitches any channel of any record with psdc_unpack_stitch:
  * bit-identical to psdc_psd on the shard itself (raw accumulators travel, normalisation happens after).
  * A record is UNTRUSTED input to the psdc_unpack_* calls: every header field is held to the range the library can produce
- * (2 <= n <= 16384, n_channels <= 4096, overlap < n, power and nenbw > 0, stage counts <= 16) and the length to what those
+ * (2 <= n <= 131072, n_channels <= 4096, overlap < n, power and nenbw > 0, stage counts <= 16) and the length to what those
  * fields imply, before anything is indexed; a record that fails is PSDC_ERR_ARG, never an out-of-bounds read.
  * psdc_readout_bytes returns 0 for dimensions outside those ranges (no such record exists). */
 size_t psdc_readout_bytes(uint32_t n, uint32_t n_channels);

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 #ifndef PSDK_HOIST_LOOKAHEAD
 #define PSDK_HOIST_LOOKAHEAD 1
 #endif
+#ifndef PSDK_EARLY_LOOKAHEAD
+#define PSDK_EARLY_LOOKAHEAD 0
+#endif
 #ifndef PSDK_HOIST_FIRST
 #define PSDK_HOIST_FIRST 0 // the six loads at the start of a run as ONE frame / f32 decision: see there
 #endif
@@ -583,67 +586,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 
         // ---- FFT of the pair ---------------------------------------------------------------
         cf vv[VT][16];
-        if constexpr (EWMA) {
-            if (job.ewma) {
-                dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
-                if constexpr (!SINGLE)
-                    dp.eb = eamp.next(job);
-            }
-        }
-        // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one
-        // exposed L2 round trip per pair where reading all table entries at their uses was nineteen.  (Issuing the
-        // batch before the decimator instead hides that one as well but keeps 26 more registers live across it:
-        // measured slower at every size, and much slower at N = 16384, whose 1024 threads spill.  The window alone in front of
-        // stage C, round 3: N = 8192 -2.7 %, Mean -10 %; N = 16384 +-0, Mean -12 % -- spills again.)
-        typename T::Seeds sd[VT];
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            const int tl = tp + THREADS * v;
-            const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
-            float4 wq0, wq1, wq2, wq3;
-            if constexpr (PSDK_ABL & 2048) { // timing only: no window loads
-                wq0 = wq1 = wq2 = wq3 = make_float4(0.5f, 0.25f + dp.ea, 0.125f, 0.75f);
-            } else {
-                wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
-            }
-            if constexpr (PSDK_HOIST_SEEDS != 0) {
-                sd[v] = sd_run[v];
-                // (opaque per pair: the products formed from the seeds must not be hoisted out of the loop with them --
-                // left alone the compiler keeps every derived twiddle of the run live and spills 200 bytes a lane)
-                asm volatile("" : "+v"(sd[v].w0.re), "+v"(sd[v].w0.im));
-            } else {
-                sd[v] = T::load_seeds(tl, tw0p);
-            }
-            window_pair<N, DETREND, EWMA, true, SINGLE>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
-                                          wq2, wq3, dp);
-            // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
-            // go one after the other between two barriers)
-            T::pass0(tl, vv[v], sd[v]);
-            T::store0(tl, vv[v], frame);
-            lane_fence();
-        }
-        __syncthreads();
-        PSDK_BSTAMP(5); // table loads + window + pass 0 + store + barrier
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            T::loadA(tp + THREADS * v, vv[v], frame);
-            typename T::SeedsA sa_ = PSDK_HOIST_SEEDS != 0 ? sda_run[v] : T::load_seeds_a(tp + THREADS * v, twap);
-            if constexpr (PSDK_HOIST_SEEDS != 0)
-                asm volatile("" : "+v"(sa_.a1.re), "+v"(sa_.a1.im), "+v"(sa_.a4.re), "+v"(sa_.a4.im));
-            T::passA(tp + THREADS * v, vv[v], sa_);
-            T::storeA(tp + THREADS * v, vv[v], frame);
-            lane_fence();
-        }
-        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during passes B and C and the
-          // next decimator's first stage -- AFTER pass A's twiddle seeds (vmcnt retires loads in order: a wait for the
-          // seeds behind these would wait for HBM); issued
-          // unconditionally (after the last pair: re-reads of pieces read before, unused) so that
-          // the compiler does not wait for them at the end of a branch
-            // (the decimator's outputs leave here too: a store issued in stage C would sit in front of the table
-            // loads in the same in-order counter, and the wait for the window would wait for its write as well)
-#pragma unroll
-            for (int r = 0; r < VT; ++r)
-                *reinterpret_cast<f2 *>(o + 2 * (tp + THREADS * r)) = yc[r];
+        auto lookahead = [&] {
             const float4 *src = more ? cnext : safe;
             const unsigned ssrc = more ? snext : safe_s;
             safe = src;
@@ -687,6 +630,75 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
                 glo[v][1] = piece(c, s, N / 4 + TEAM);
 #endif
             }
+        };
+        if constexpr (EWMA) {
+            if (job.ewma) {
+                dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
+                if constexpr (!SINGLE)
+                    dp.eb = eamp.next(job);
+            }
+        }
+        // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one
+        // exposed L2 round trip per pair where reading all table entries at their uses was nineteen.  (Issuing the
+        // batch before the decimator instead hides that one as well but keeps 26 more registers live across it:
+        // measured slower at every size, and much slower at N = 16384, whose 1024 threads spill.  The window alone in front of
+        // stage C, round 3: N = 8192 -2.7 %, Mean -10 %; N = 16384 +-0, Mean -12 % -- spills again.)
+        typename T::Seeds sd[VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int tl = tp + THREADS * v;
+            const float4 *wp = reinterpret_cast<const float4 *>(winp) + tl;
+            float4 wq0, wq1, wq2, wq3;
+            if constexpr (PSDK_ABL & 2048) { // timing only: no window loads
+                wq0 = wq1 = wq2 = wq3 = make_float4(0.5f, 0.25f + dp.ea, 0.125f, 0.75f);
+            } else {
+                wq0 = wp[0], wq1 = wp[TEAM], wq2 = wp[2 * TEAM], wq3 = wp[3 * TEAM];
+            }
+            if constexpr (PSDK_HOIST_SEEDS != 0) {
+                sd[v] = sd_run[v];
+                // (opaque per pair: the products formed from the seeds must not be hoisted out of the loop with them --
+                // left alone the compiler keeps every derived twiddle of the run live and spills 200 bytes a lane)
+                asm volatile("" : "+v"(sd[v].w0.re), "+v"(sd[v].w0.im));
+            } else {
+                sd[v] = T::load_seeds(tl, tw0p);
+            }
+            window_pair<N, DETREND, EWMA, true, SINGLE>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
+                                          wq2, wq3, dp);
+            // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
+            // go one after the other between two barriers)
+            T::pass0(tl, vv[v], sd[v]);
+            T::store0(tl, vv[v], frame);
+            lane_fence();
+        }
+        // -DPSDK_EARLY_LOOKAHEAD=1 (experiment): the look-ahead loads here, a pass earlier -- the twiddle seeds are held across the
+        // run since round 3, so nothing behind these loads waits on vmcnt any more; their 16 destination registers are then live
+        // through passes 0 and A
+        if constexpr (PSDK_EARLY_LOOKAHEAD != 0)
+            lookahead();
+        __syncthreads();
+        PSDK_BSTAMP(5); // table loads + window + pass 0 + store + barrier
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            T::loadA(tp + THREADS * v, vv[v], frame);
+            typename T::SeedsA sa_ = PSDK_HOIST_SEEDS != 0 ? sda_run[v] : T::load_seeds_a(tp + THREADS * v, twap);
+            if constexpr (PSDK_HOIST_SEEDS != 0)
+                asm volatile("" : "+v"(sa_.a1.re), "+v"(sa_.a1.im), "+v"(sa_.a4.re), "+v"(sa_.a4.im));
+            T::passA(tp + THREADS * v, vv[v], sa_);
+            T::storeA(tp + THREADS * v, vv[v], frame);
+            lane_fence();
+        }
+        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during passes B and C and the
+          // next decimator's first stage -- AFTER pass A's twiddle seeds (vmcnt retires loads in order: a wait for the
+          // seeds behind these would wait for HBM); issued
+          // unconditionally (after the last pair: re-reads of pieces read before, unused) so that
+          // the compiler does not wait for them at the end of a branch
+            // (the decimator's outputs leave here too: a store issued in stage C would sit in front of the table
+            // loads in the same in-order counter, and the wait for the window would wait for its write as well)
+#pragma unroll
+            for (int r = 0; r < VT; ++r)
+                *reinterpret_cast<f2 *>(o + 2 * (tp + THREADS * r)) = yc[r];
+            if constexpr (PSDK_EARLY_LOOKAHEAD == 0)
+                lookahead();
         }
         PSDK_FFT_BARRIER();
         PSDK_BSTAMP(6); // pass A (seeds from L2) + output store + look-ahead issue + barrier

@@ -770,6 +770,8 @@ hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_
 
 int welch_segments_per_tile(int n)
 {
+    if (bigfft_size(n)) // one tile, one workgroup row per job: the segments go pair by pair through global memory (bigfft.hip)
+        return 1 << 20;
     switch (bluestein_size(n)) { // not a power of two: the tile of the chirp-z kernel of its transform size
 #define PSDK_CASE(MM) \
     case MM:          \

@@ -117,6 +117,8 @@ struct psdc_handle {
     cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels
     cf *d_tw3g = nullptr;                    // twiddle seeds of the three-pass kernels (N = 2048, 4096)
     cf *d_chirp = nullptr, *d_bhat = nullptr; // chirp-z tables of a size that is not a power of two (launch_welch)
+    cf *d_bigfft = nullptr;                   // n > 16384: the ping-pong frames of the global-memory FFT (launch_welch_big)
+    size_t bigfft_elems = 0;
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
@@ -386,7 +388,9 @@ int resolve_device(int device)
 
 // powers of two 16 ... 16384 (every kernel), or any other size 16 < n <= 8192 (rustfft plans any length, src/psd.rs:418): those
 // run the generic kernels with the DFT in chirp-z form (kernels.hip welch_bluestein_kernel)
-bool valid_n(uint32_t n) { return n >= 16 && n <= 16384 && ((n & (n - 1)) == 0 || bluestein_size((int)n) != 0); }
+// ... and the powers of two 32768 ... 131072 through a global-memory FFT (bigfft.hip: slow, but every size the reference's own
+// stack frames let it run)
+bool valid_n(uint32_t n) { return n >= 16 && n <= (uint32_t)BIGFFT_MAX_N && ((n & (n - 1)) == 0 || bluestein_size((int)n) != 0); }
 
 // PsdStage::gain (src/psd.rs:279-283): (N/2 * count) as f32, then two f32 multiplies.  The
 // reference forms the product in u32, which overflows (panic in debug builds, wrap-around in
@@ -1242,7 +1246,10 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         const bool first = (i <= (size_t)MAX_JOBS);
         if (!prof_fused && (rc = prof_begin(pe, true)))
             return rc;
-        HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->d_chirp, h->d_bhat, h->stream));
+        if (bigfft_size((int)h->n))
+            HIPCHK(h, launch_welch_big((int)h->n, wb, h->d_win, h->d_tw, h->d_bigfft, h->bigfft_elems, h->stream));
+        else
+            HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->d_chirp, h->d_bhat, h->stream));
         if (!prof_fused && (rc = prof_end(pe, first, true)))
             return rc;
     }
@@ -1569,7 +1576,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
 {
     device = resolve_device(device);
     if (!valid_n(n) || !welch_supported((int)n)) {
-        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 16384] or any size in [16, 8192]");
+        fail(nullptr, PSDC_ERR_ARG, "psdc_create: n must be a power of two in [16, 131072] or any size in [16, 8192]");
         return nullptr;
     }
     if (window_kind != PSDC_WINDOW_CUSTOM && !window_consts(n, window_kind, &wc)) {
@@ -1703,7 +1710,13 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
     if ((e = hipMalloc(&h->d_pool, sizeof(float) * (size_t)n_channels * MAX_STAGES * 2 * h->pool_cap)) != hipSuccess)
         return dev_fail(e, "hipMalloc(stream pool)");
     // partial slab for a full round (grows only if many channels need more)
-    h->partial_cap = (size_t)(fused_max_blocks((int)n) + WELCH_MAX_BLOCKS + 4 * MAX_JOBS) * n;
+    h->partial_cap = bigfft_size((int)n) ? (size_t)MAX_JOBS * n // (one row per job at these sizes)
+                                         : (size_t)(fused_max_blocks((int)n) + WELCH_MAX_BLOCKS + 4 * MAX_JOBS) * n;
+    if (bigfft_size((int)n)) {
+        h->bigfft_elems = BIGFFT_SCRATCH_ELEMS;
+        if ((e = hipMalloc(&h->d_bigfft, sizeof(cf) * h->bigfft_elems)) != hipSuccess)
+            return dev_fail(e, "hipMalloc(big FFT frames)");
+    }
     if ((e = hipMalloc(&h->d_partial, sizeof(float) * h->partial_cap)) != hipSuccess)
         return dev_fail(e, "hipMalloc(partials)");
     {
@@ -1735,7 +1748,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
 const char *check_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap, int *kind, WindowConsts *wc)
 {
     if (!valid_n(n))
-        return "n must be a power of two in [16, 16384]";
+        return "n must be a power of two in [16, 131072] or any size in [16, 8192]";
     if (!win)
         return "null window";
     if (overlap >= n || (n - overlap) % 8 != 0)
@@ -1861,6 +1874,8 @@ void psdc_destroy(psdc_handle *h)
         (void)hipFree(h->d_chirp);
     if (h->d_bhat)
         (void)hipFree(h->d_bhat);
+    if (h->d_bigfft)
+        (void)hipFree(h->d_bigfft);
     if (h->ev_upload)
         (void)hipEventDestroy(h->ev_upload);
     if (h->ev_post)
@@ -2818,7 +2833,7 @@ size_t pack_channel_bytes(uint32_t n) { return 8 + sizeof(PackStage) * MAX_STAGE
 // transport, so nothing in it is trusted: every field is held to the range the library itself can produce BEFORE it enters a size
 // computation (n a supported FFT size -- psdc_pack_init also admits the small powers of two the host-only tests use --,
 // n_channels <= 4096 as in psdc_create, overlap < n), and the length test is a division, which cannot wrap.
-constexpr uint32_t PACK_MAX_N = 16384, PACK_MAX_CHANNELS = 4096;
+constexpr uint32_t PACK_MAX_N = (uint32_t)BIGFFT_MAX_N, PACK_MAX_CHANNELS = 4096;
 bool pack_dims_ok(uint32_t n, uint32_t n_channels, uint64_t overlap)
 {
     return n >= 2 && n <= PACK_MAX_N && n_channels <= PACK_MAX_CHANNELS && overlap < n;

@@ -171,8 +171,8 @@ void new_scenario(const std::string &ctx, int cap_blocks)
 void scenario_stress(uint64_t seed)
 {
     Rng r(seed);
-    static const uint32_t sizes[] = {64, 256, 512, 1024, 1024, 2048, 4096, 8192, 16384, 80, 1200};
-    const uint32_t n = sizes[seed % 11];
+    static const uint32_t sizes[] = {64, 256, 512, 1024, 1024, 2048, 4096, 8192, 16384, 80, 1200, 32768, 512};
+    const uint32_t n = sizes[seed % 13];
     const bool rect = r.f() < 0.15; // overlap 0: the generic kernels only
     const uint32_t overlap = rect ? 0 : n / 2;
     const int nch = (int)r.u(1, 4);

@@ -65,8 +65,11 @@ int bluestein_size(int n)
         m <<= 1;
     return m;
 }
+bool bigfft_size(int n) { return n > 16384 && n <= BIGFFT_MAX_N && (n & (n - 1)) == 0; }
 int welch_segments_per_tile(int n)
 {
+    if (bigfft_size(n))
+        return 1 << 20;
     if (bluestein_size(n))
         return 32;
     return (n >= 16 && n <= 16384 && (n & (n - 1)) == 0) ? 32 : 0;
@@ -177,6 +180,20 @@ hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *
             error("welch launch: %d workgroups named by the jobs, grid of %d", blocks, b.nblocks);
     });
     return hipSuccess;
+}
+
+// ---- bigfft.hip (n > 16384): the same jobs, ONE partial row each, scratch for at least one pair -----------------------
+hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, hipStream_t s)
+{
+    if (!bigfft_size(n) || !scratch || scratch_elems < 2 * (size_t)n)
+        return hipErrorInvalidValue;
+    for (int ji = 0; ji < b.njobs; ++ji)
+        if (b.jobs[ji].nblocks != 1 || b.jobs[ji].fspan >= 0)
+            error("big-FFT welch job %d: %d partial rows / frame source %d", ji, b.jobs[ji].nblocks, b.jobs[ji].fspan);
+    volatile cf *sc = scratch; // (the frames exist: first and last element)
+    sc[0].re = 0.0f;
+    sc[scratch_elems - 1].im = 0.0f;
+    return launch_welch(n, b, win, tw, nullptr, nullptr, s);
 }
 
 // ---- fused_kernel / bigfused_kernel / bigfused3_kernel -------------------------------------------------------------

@@ -75,3 +75,30 @@ def test_size_limits(pkg, gpu_required):
     for bad in (8, 15, 8200, 16400, 20000):  # below 16, or not a power of two above 8192, or above 16384
         with pytest.raises(pkg.PsdError):
             pkg.PsdCascade(bad)
+
+
+@pytest.mark.parametrize("n,detrend,avg", [(32768, "none", None), (32768, "mean", (5, 200)), (65536, "span", None),
+                                           (65536, "midpoint", (3, 40)), (131072, "none", None)])
+def test_fft_sizes_above_an_lds_frame(pkg, ora, gpu_required, n, detrend, avg):
+    """Powers of two 32768 ... 131072 (`FftPlanner::plan_fft_forward(N)` takes any N, src/psd.rs:417-418; the reference's own stack
+    frames bound what it can run): the generic path with a Stockham FFT through global memory (csrc/bigfft.hip).  White noise,
+    host-fed in odd chunks then device-fed, a read-out in between: counters exactly, every stage against the f64 oracle (pure 1e-5
+    where a plain-sum stage has >= 4 averages and no detrend nulls a bin)."""
+    import torch
+    total = 21 * n + 8 * 13
+    x = pkg.noise_host(total, seed=1300 + n // 1024)
+    g = pkg.PsdCascadeBank(n)
+    g.set_detrend(pkg.Detrend[detrend.upper()])
+    av = pkg.AvgOpts(*avg) if avg else None
+    if av:
+        g.set_avg(av)
+    cut = (total // 3) | 1
+    g.process(0, x[:cut])
+    assert g.stage_info(0, 0)["count"] == min((cut - n) // (n // 2) + 1, (min(av.count, av.limit) + 1) if av else 1 << 40)
+    d = torch.from_numpy(x[cut:]).cuda()
+    g.process_device(0, d.data_ptr(), total - cut)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, avg=av, what=f"N={n} {detrend} avg={avg}",
+                         pure_min_count=4 if (av is None and detrend == "none") else None)
+    g.close()
+    with pytest.raises(pkg.PsdError):
+        pkg.PsdCascadeBank(262144)  # beyond the largest size
