@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -103,8 +104,12 @@ __device__ __forceinline__ float team_sum(float v)
 // FRAMES: as in bigfused_impl.h -- jobs with fspan >= 0 read their stream in place from AdcDac frames (8-byte buffer loads of
 // four wire words, converted in the register group once the loads have landed); separate kernels, so the f32-only launches keep
 // their instruction stream and registers.
-// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair).
-template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
+// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair).  1: every segment is transformed
+// by itself with a zero imaginary part.  2 (DOUBLE): the proper two-for-one of two DISJOINT segments -- step 2i windows segment
+// 2i into sixteen kept registers, step 2i + 1 windows segment 2i + 1 into the imaginary parts and runs the ONE transform of
+// both (|X_a[k]|^2 + |X_b[k]|^2 = 1/2 (|Z[k]|^2 + |Z[N-k]|^2), folded by post_kernel as ever): half the FFT work per sample of
+// the Hann path; the decimator runs every step as before.  Jobs and runs hold an even number of segments (the planner sees to it).
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, int SINGLE = 0>
 __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVES_PER_SIMD) void fused_kernel(
     const FusedBatch batch, const float *__restrict__ win)
 {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
+            eamp.init(job, job.step0 + (SINGLE != 0 ? 1 : 2) * p0);
     }
     PSDK_STAMP(10); // first loads issued + warm-up
     // One pair p.  Register groups of two float4 each: lo/up = lower/upper half of chunk p,
@@ -330,8 +335,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     // they are dead: the upper half of chunk p + 1 is loaded into `up` and the lower half of
     // chunk p + 2 into `lo`, in flight during the FFT passes.  For pair p + 1 the roles are
     // (lo, up, nl) <- (nl, up, lo).
+    float keep[16]; // DOUBLE: the windowed segment of the even step, until the odd step's transform
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        keep[s] = 0.0f;
     auto pair_step = [&](G4(&glo)[2], G4(&gup)[2], G4(&gnl)[2], const float4 *cnext, unsigned snext, bool more,
-                         float *o, int p) {
+                         float *o, int p, auto odd_step) {
+        constexpr bool DOUBLE = SINGLE == 2, ODD = decltype(odd_step)::value;
         // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
         // these copies in place -- and their groups are reloaded further down
         float4 lo[2] = {glo[0].f(), glo[1].f()}, up[2] = {gup[0].f(), gup[1].f()};
@@ -497,11 +507,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             if constexpr (EWMA) {
                 if (job.ewma) {
                     dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
-                    if constexpr (!SINGLE)
+                    if constexpr (SINGLE == 0)
                         dp.eb = eamp.next(job);
                 }
             }
-            window_pair<N, DETREND, EWMA, true, SINGLE>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
+            window_pair<N, DETREND, EWMA, true, SINGLE != 0>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],
                                           s_win[2 * TEAM + tl], s_win[3 * TEAM + tl], dp);
         }
         { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during the FFT.  Issued
@@ -568,6 +578,16 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             asm volatile("" ::"v"(d));
         }
 #endif
+        if constexpr (DOUBLE && !ODD) { // the even step keeps its windowed segment; no transform
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                keep[s] = v[s].re;
+        } else {
+        if constexpr (DOUBLE) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                v[s] = {keep[s], v[s].re};
+        }
         T::pass0(tl, v, s_tw0);
         T::store0(tl, v, frame);
         wave_sync();
@@ -587,6 +607,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             q[s] = fmaf(v[s].re, v[s].re, fmaf(v[s].im, v[s].im, q[s]));
+        } // (DOUBLE: odd step)
         if constexpr (FRAMES) { // the look-ahead groups hold raw wire words: to volts before the next pair reads them
             volts(gup[0]);
             volts(gup[1]);
@@ -602,13 +623,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         if constexpr (PSDK_ABL & 2048) // (2048: the output stream rounded down to a 128-byte boundary -- what its alignment costs)
             o = reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(o) & ~(uintptr_t)127);
         for (int i = 0; i < nrun; i += 2) {
-            pair_step(ga, gb, gc, cp + N / 4, sp + N, i + 1 < nrun, o, p0 + i);
+            pair_step(ga, gb, gc, cp + N / 4, sp + N, i + 1 < nrun, o, p0 + i, std::false_type{});
             cp += N / 4;
             sp += N;
             if (!(PSDK_ABL & 256)) // (256: every pair of a run stores to the run's first N/8 outputs -- the store instructions without their traffic)
                 o += N / 8;
             if (i + 1 < nrun) {
-                pair_step(gc, gb, ga, cp + N / 4, sp + N, i + 2 < nrun, o, p0 + i + 1);
+                pair_step(gc, gb, ga, cp + N / 4, sp + N, i + 2 < nrun, o, p0 + i + 1, std::true_type{});
                 cp += N / 4;
                 sp += N;
                 if (!(PSDK_ABL & 256))
@@ -648,6 +669,9 @@ bool fused_supported(int n)
 }
 
 bool fused_frames_supported(int n) { return fused_supported(n); }
+
+// overlap 0: the sizes whose kernels have the DOUBLE form (FusedBatch::single == 2)
+bool fused_double_supported(int n) { return n == 256 || n == 512 || n == 1024; }
 
 int fused_pairs_per_block(int n, int run)
 {
@@ -761,10 +785,14 @@ static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStrea
         break;
 #define PSDK_FUSED_SINGLE(D)                                                                              \
     case D:                                                                                               \
-        if (ew_)                                                                                          \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
+        if (b.single == 2 && ew_)                                                                         \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 2>), grid, block, 0, s, ea, eb, 0, b, win);  \
+        else if (b.single == 2)                                                                           \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 2>), grid, block, 0, s, ea, eb, 0, b, win); \
+        else if (ew_)                                                                                     \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 1>), grid, block, 0, s, ea, eb, 0, b, win);  \
         else                                                                                              \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win); \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 1>), grid, block, 0, s, ea, eb, 0, b, win); \
         break;
     if (b.single) {
         if (b.any_frames)

@@ -129,7 +129,9 @@ struct FusedBatch {
     int any_frames; // some job reads AdcDac frames (the kernels built with the frame loads run this launch)
     // overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table with overlap 0): a "pair" is ONE segment -- pair i =
     // segment seg_a + i = samples src[N i .. N i + N), transformed with a zero imaginary part; the N samples it decimates are
-    // still src[N i + N/2 .. N i + 3N/2), so the stream is consumed exactly as with half-overlapped pairs (the SINGLE kernels)
+    // still src[N i + N/2 .. N i + 3N/2), so the stream is consumed exactly as with half-overlapped pairs (the SINGLE kernels).
+    // 2 (N <= 1024): as 1, but segments 2i and 2i + 1 share ONE transform (the two-for-one of two disjoint segments); every job
+    // then holds an even number of pairs and `run` is even
     int single;
     // frame jobs come first in the launch, four by four (the traces of one span, equal workgroup counts): group g
     // = workgroups [fg_begin[g], fg_begin[g] + 4 fg_nb[g]); the kernel deals a group's workgroups so that the four
@@ -189,6 +191,7 @@ bool bigfft_size(int n);
 hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, hipStream_t s);
 bool fused_supported(int n);                 // N = 256 ... 16384
 bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
+bool fused_double_supported(int n);          // overlap 0: sizes whose kernel transforms two disjoint segments at once
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
 int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
 int fused_block_threads(int n);              // threads of one such workgroup

@@ -706,6 +706,10 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     const int spt = welch_segments_per_tile((int)h->n);
     const int fmode = fused_supported((int)h->n) ? fused_window(h) : 0;
     const bool fast_ok = fmode != 0, single = fmode == 2;
+    // overlap 0 at the team-kernel sizes: two disjoint segments per transform (FusedBatch::single == 2) -- jobs and runs then hold
+    // an even number of single-segment "pairs".  $PSDC_NO_DOUBLE: one segment per transform everywhere (A/B aid)
+    static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
+    const bool dbl = single && !no_double && fused_double_supported((int)h->n);
     const unsigned fstep = single ? 1 : 2;   // segments per fused "pair"
     const uint64_t half = (uint64_t)h->n / 2; // a fused run starting at segment j decimates from sample j hop + N/2 on
     auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + half; };
@@ -983,6 +987,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 // (the last segment of a span -- of a round -- is left to the generic kernels with its half chunk)
                 const uint64_t lim = 8 * sp.m_b;
                 np = run_new0(fs) + h->n <= lim ? std::min<uint64_t>(np, (lim - run_new0(fs)) / h->n) : 0;
+                if (dbl)
+                    np &= ~(uint64_t)1; // (the odd segment goes with the span's last one: generic kernels)
             }
             const uint64_t fofs = (uint64_t)g.hop * fs - sp.src_base; // samples of this span in front of the pairs
             const float *fsrc = framed ? nullptr : sp.src + fofs;
@@ -1117,7 +1123,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             FusedJob &j = fjobs[i].j;
             const uint64_t np = (uint64_t)j.npairs;
             const uint64_t nb = small_at(np, R) ? 1 : (np + R * teams - 1) / (R * teams);
-            const uint64_t run = (np + nb * teams - 1) / (nb * teams); // evened out within the job (<= R)
+            uint64_t run = (np + nb * teams - 1) / (nb * teams); // evened out within the job (<= R)
+            if (dbl)
+                run += run & 1; // every team starts on an even segment and holds whole segment pairs
             j.run = (int)run;
             j.nblocks = (int)((np + run * teams - 1) / (run * teams));
             blocks_total += (size_t)j.nblocks;
@@ -1191,7 +1199,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     for (size_t i = 0; i < fjobs.size();) {
         FusedBatch fb{};
         fb.detrend = h->detrend;
-        fb.single = single ? 1 : 0;
+        fb.single = dbl ? 2 : single ? 1 : 0;
         FspanMap fm(fb.fspans);
         for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
             FusedJob j = fjobs[i].j;

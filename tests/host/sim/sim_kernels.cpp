@@ -20,6 +20,7 @@ using sim::world;
 // ---- geometry the planner asks for (fused.hip / kernels.hip) -----------------------------------------------------
 bool fused_supported(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
 bool fused_frames_supported(int n) { return fused_supported(n); }
+bool fused_double_supported(int n) { return n == 256 || n == 512 || n == 1024; }
 static int fused_teams(int n) { return n >= 2048 ? 1 : FUSED_WAVES * (64 / (n / 16)); } // FusedGeo<N>::TEAMS
 int fused_pairs_per_block(int n, int run) { return fused_supported(n) ? fused_teams(n) * run : 0; }
 int fused_block_threads(int n) { return n >= 2048 ? n / 16 : FUSED_WAVES * 64; }
@@ -232,6 +233,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
                 world().fused_frame_jobs += 1;
             if (fr && b.single)
                 error("fused job %d reads frames in a single-segment launch", ji);
+            if (b.single == 2 && ((job.npairs & 1) || (job.run & 1) || !fused_double_supported(n)))
+                error("fused job %d: %d segments in runs of %d for the two-segments-per-transform kernels (n = %d)", ji, job.npairs, job.run, n);
             if (fr && !b.any_frames)
                 error("fused job %d reads frames in a launch without any_frames", ji);
             if (job.ewma && !b.any_ewma)
