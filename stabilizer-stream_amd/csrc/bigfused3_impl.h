@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "fft_block3.h"
 #include "frames.h"
 #include "fused_common.h"
@@ -87,7 +89,8 @@ __device__ __forceinline__ void window_pair3(cf (&v)[16], int tl, const g8 &lo, 
     }
 }
 
-template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
+// SINGLE (overlap 0): 1 = one segment per transform, 2 = two disjoint segments per transform (fused.hip says how)
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, int SINGLE = 0>
 __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused3_kernel(const FusedBatch batch,
                                                                            const float *__restrict__ win,
                                                                            const cf *__restrict__ tw0g)
@@ -291,12 +294,17 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
+            eamp.init(job, job.step0 + (SINGLE != 0 ? 1 : 2) * p0);
     }
     // the lane's twiddle seeds, held across the run (opaque per pair: see bigfused_impl.h)
     const typename T::Seeds sd_run = T::load_seeds(tp, tw0g);
 
-    auto pair_step = [&](G8 &glo, G8 &gup, G8 &gnl, const float *cnext, unsigned snext, bool more, float *o) {
+    float keep[16]; // SINGLE == 2: the windowed segment of the even step, until the odd step's transform
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        keep[s] = 0.0f;
+    auto pair_step = [&](G8 &glo, G8 &gup, G8 &gnl, const float *cnext, unsigned snext, bool more, float *o, auto odd_step) {
+        constexpr bool DOUBLE = SINGLE == 2, ODD = decltype(odd_step)::value;
         // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
         // these copies in place -- and their groups are reloaded further down
         g8 lo = samples(glo), up = samples(gup);
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         if constexpr (EWMA) {
             if (job.ewma) {
                 dp.ea = eamp.next(job);
-                if constexpr (!SINGLE)
+                if constexpr (SINGLE == 0)
                     dp.eb = eamp.next(job);
             }
         }
@@ -423,17 +431,12 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
 #pragma unroll
             for (int m = 0; m < 16; ++m)
                 w[m] = (PSDK_ABL3 & 2048) ? 0.5f + dp.ea * (float)m : winp[tp + (N / 16) * m]; // (2048: timing only, no window loads)
-            window_pair3<N, DETREND, EWMA, SINGLE>(vv, tp, lo, up, nl, w, dp);
+            window_pair3<N, DETREND, EWMA, SINGLE != 0>(vv, tp, lo, up, nl, w, dp);
         }
-        {
-            typename T::Seeds sd = sd_run;
-            asm volatile("" : "+v"(sd.w1.re), "+v"(sd.w1.im), "+v"(sd.w4.re), "+v"(sd.w4.im));
-            T::pass0(vv, sd);
-        }
-        T::store0(tp, vv, frame);
-        { // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during passes 1 and 2 and the next decimator's first
-          // stage; issued unconditionally (after the last pair: re-reads of pieces read before, unused).  The decimator's
-          // outputs leave here too (behind the window loads in the in-order counter).
+        // chunk p + 1 upper -> up, chunk p + 2 lower -> lo, in flight during passes 1 and 2 and the next decimator's first
+        // stage; issued unconditionally (after the last pair: re-reads of pieces read before, unused).  The decimator's
+        // outputs leave here too (behind the window loads in the in-order counter).
+        auto lookahead = [&] {
             *reinterpret_cast<f2 *>(o + 2 * tp) = yc;
             const float *src = more ? cnext : safe;
             const unsigned ssrc = more ? snext : safe_s;
@@ -441,7 +444,27 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             safe_s = ssrc;
             load8(gup, src + N / 2, ssrc + N / 2);
             load8(glo, src + N, ssrc + N);
+        };
+        if constexpr (DOUBLE && !ODD) { // the even step keeps its windowed segment: no transform (and no frame use: the barrier
+                                        // behind stage C already separates this pair's decimator from the next one's)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                keep[s] = vv[s].re;
+            lookahead();
+            return;
         }
+        if constexpr (DOUBLE) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                vv[s] = {keep[s], vv[s].re};
+        }
+        {
+            typename T::Seeds sd = sd_run;
+            asm volatile("" : "+v"(sd.w1.re), "+v"(sd.w1.im), "+v"(sd.w4.re), "+v"(sd.w4.im));
+            T::pass0(vv, sd);
+        }
+        T::store0(tp, vv, frame);
+        lookahead();
         __syncthreads();
         T::load1(tp, vv, frame);
         T::pass1(tp, vv, s_tw1);
@@ -462,12 +485,12 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
         for (int p = p0; p < p1; p += 2) {
-            pair_step(ga, gb, gc, cp + N, sp + N, p + 1 < p1, o);
+            pair_step(ga, gb, gc, cp + N, sp + N, p + 1 < p1, o, std::false_type{});
             cp += N;
             sp += N;
             o += N / 8;
             if (p + 1 < p1) {
-                pair_step(gc, gb, ga, cp + N, sp + N, p + 2 < p1, o);
+                pair_step(gc, gb, ga, cp + N, sp + N, p + 2 < p1, o, std::true_type{});
                 cp += N;
                 sp += N;
                 o += N / 8;
@@ -500,10 +523,14 @@ hipError_t launch_bigfused3_n(const FusedBatch &b, const float *win, const cf *t
         break;
 #define PSDK_BIG3_SINGLE(D)                                                                                   \
     case D:                                                                                                   \
-        if (ew_)                                                                                              \
-            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
+        if (b.single == 2 && ew_)                                                                             \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true, false, 2>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
+        else if (b.single == 2)                                                                               \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false, false, 2>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
+        else if (ew_)                                                                                         \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, true, false, 1>), grid, block, 0, s, ea, eb, 0, b, win, tw0g);  \
         else                                                                                                  \
-            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
+            hipExtLaunchKernelGGL((bigfused3_kernel<N, D, false, false, 1>), grid, block, 0, s, ea, eb, 0, b, win, tw0g); \
         break;
     if (b.single) {
         if (b.any_frames)
