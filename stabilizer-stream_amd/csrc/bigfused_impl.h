@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "fft_block.h"
 #include "frames.h"
 #include "fused_common.h"
@@ -78,8 +80,9 @@ struct BigGeo : FusedDec<N, NOX> {
 // the register group until the loads have landed and converted there (i16 -> f32 x LSB, DAC words offset binary, :28-35,
 // :64,:75) -- the four f32 streams of the traces never exist in memory.  Built as separate kernels: the f32-only launches
 // keep their instruction stream and registers.
-// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair).
-template <int N, int DETREND, bool EWMA, bool FRAMES = false, bool SINGLE = false>
+// SINGLE: overlap 0 -- one segment per "pair" (FusedBatch::single; fused_common.h window_pair); 2: two disjoint segments per
+// transform (fused.hip says how).
+template <int N, int DETREND, bool EWMA, bool FRAMES = false, int SINGLE = 0>
 __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_kernel(const FusedBatch batch,
                                                                          const float *__restrict__ win,
                                                                          const cf *__restrict__ tw0g,
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     EwmaAmp eamp;
     if constexpr (EWMA) {
         if (job.ewma)
-            eamp.init(job, job.step0 + (SINGLE ? 1 : 2) * p0);
+            eamp.init(job, job.step0 + (SINGLE != 0 ? 1 : 2) * p0);
     }
 
     // The lane's own twiddle seeds (W_N^(4 tl); W_L1^s, W_L1^(4 s): fft_block.h) do not change from pair to pair: six registers
@@ -382,8 +385,15 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         load_halo(p0);
 
     // one pair; register groups as in fused.hip: (lo, up) = chunk p, nl = lower half of chunk p + 1
+    float keep[VT][16]; // SINGLE == 2: the windowed segment of the even step, until the odd step's transform
+#pragma unroll
+    for (int v = 0; v < VT; ++v)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            keep[v][s] = 0.0f;
     auto pair_step = [&](G4(&glo)[VT][2], G4(&gup)[VT][2], G4(&gnl)[VT][2], const float4 *cnext, unsigned snext,
-                         bool more, float *o, int p) {
+                         bool more, float *o, int p, auto odd_step) {
+        constexpr bool DOUBLE = SINGLE == 2, ODD = decltype(odd_step)::value;
         // the samples of this pair (converted at the end of the pair before): lo / up are dead once windowed -- Mean centres
         // these copies in place -- and their groups are reloaded further down
         float4 lo[VT][2], up[VT][2], nl[VT][2];
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         if constexpr (EWMA) {
             if (job.ewma) {
                 dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
-                if constexpr (!SINGLE)
+                if constexpr (SINGLE == 0)
                     dp.eb = eamp.next(job);
             }
         }
@@ -662,13 +672,34 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             } else {
                 sd[v] = T::load_seeds(tl, tw0p);
             }
-            window_pair<N, DETREND, EWMA, true, SINGLE>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
+            window_pair<N, DETREND, EWMA, true, SINGLE != 0>(vv[v], tl, lo[v][0], lo[v][1], up[v][0], up[v][1], nl[v][0], nl[v][1], wq0, wq1,
                                           wq2, wq3, dp);
-            // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
-            // go one after the other between two barriers)
-            T::pass0(tl, vv[v], sd[v]);
-            T::store0(tl, vv[v], frame);
+            if constexpr (DOUBLE && !ODD) { // the even step keeps its windowed segment: no transform
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    keep[v][s] = vv[v][s].re;
+            } else {
+                if constexpr (DOUBLE) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        vv[v][s] = {keep[v][s], vv[v][s].re};
+                }
+                // (every lane rewrites exactly the frame positions it read, so the lanes of a thread
+                // go one after the other between two barriers)
+                T::pass0(tl, vv[v], sd[v]);
+                T::store0(tl, vv[v], frame);
+            }
             lane_fence();
+        }
+        if constexpr (DOUBLE && !ODD) { // (no frame use: the barrier behind stage C already separates this pair's decimator from
+                                        // the next one's; the decimator's outputs and the look-ahead loads leave as in an odd step)
+#pragma unroll
+            for (int r = 0; r < VT; ++r)
+                *reinterpret_cast<f2 *>(o + 2 * (tp + THREADS * r)) = yc[r];
+            lookahead();
+            if constexpr (REGA && PSDK_REGA_PREFETCH != 0)
+                load_halo(more ? p + 1 : p);
+            return;
         }
         // -DPSDK_EARLY_LOOKAHEAD=1 (experiment): the look-ahead loads here, a pass earlier -- the twiddle seeds are held across the
         // run since round 3, so nothing behind these loads waits on vmcnt any more; their 16 destination registers are then live
@@ -745,12 +776,12 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
     {
         float *o = job.dst + (size_t)p0 * (N / 8);
         for (int p = p0; p < p1; p += 2) {
-            pair_step(ga, gb, gc, cp + N / 4, sp + N, p + 1 < p1, o, p);
+            pair_step(ga, gb, gc, cp + N / 4, sp + N, p + 1 < p1, o, p, std::false_type{});
             cp += N / 4;
             sp += N;
             o += N / 8;
             if (p + 1 < p1) {
-                pair_step(gc, gb, ga, cp + N / 4, sp + N, p + 2 < p1, o, p + 1);
+                pair_step(gc, gb, ga, cp + N / 4, sp + N, p + 2 < p1, o, p + 1, std::true_type{});
                 cp += N / 4;
                 sp += N;
                 o += N / 8;
@@ -793,10 +824,14 @@ hipError_t launch_bigfused_n(const FusedBatch &b, const float *win, const cf *tw
         break;
 #define PSDK_BIG_SINGLE(D)                                                                                          \
     case D:                                                                                                         \
-        if (ew_)                                                                                                    \
-            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
+        if (b.single == 2 && ew_)                                                                                   \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true, false, 2>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
+        else if (b.single == 2)                                                                                     \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false, false, 2>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
+        else if (ew_)                                                                                               \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, true, false, 1>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag);  \
         else                                                                                                        \
-            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false, false, true>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
+            hipExtLaunchKernelGGL((bigfused_kernel<N, D, false, false, 1>), grid, block, 0, s, ea, eb, 0, b, win, tw0g, twag); \
         break;
     if (b.single) {
         if (b.any_frames)

@@ -671,7 +671,7 @@ bool fused_supported(int n)
 bool fused_frames_supported(int n) { return fused_supported(n); }
 
 // overlap 0: the sizes whose kernels have the DOUBLE form (FusedBatch::single == 2)
-bool fused_double_supported(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+bool fused_double_supported(int n) { return fused_supported(n); }
 
 int fused_pairs_per_block(int n, int run)
 {

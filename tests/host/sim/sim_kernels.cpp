@@ -20,7 +20,7 @@ using sim::world;
 // ---- geometry the planner asks for (fused.hip / kernels.hip) -----------------------------------------------------
 bool fused_supported(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
 bool fused_frames_supported(int n) { return fused_supported(n); }
-bool fused_double_supported(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+bool fused_double_supported(int n) { return fused_supported(n); }
 static int fused_teams(int n) { return n >= 2048 ? 1 : FUSED_WAVES * (64 / (n / 16)); } // FusedGeo<N>::TEAMS
 int fused_pairs_per_block(int n, int run) { return fused_supported(n) ? fused_teams(n) * run : 0; }
 int fused_block_threads(int n) { return n >= 2048 ? n / 16 : FUSED_WAVES * 64; }
