@@ -170,14 +170,18 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
     // with (dq_j, dr_j) = divmod((H/8) j, batches) the same for every lane, and a wrap of the batch index into the next frame
     // costs exactly that frame's 8 header bytes (frame_size = 8 + 64 batches): ONE division per group and lane, then
     // offset_j = offset_0 + (dq_j frame_size + 64 dr_j) + (b0 + dr_j >= batches ? 8 : 0) -- four plain VALU operations a load.
-    unsigned fdr[8], fdc[8];
+    // (round 4: the wrap test as ONE compare of the lane's batch index with a uniform threshold, batches - dr_j, selecting between
+    // offset_0 and offset_0 + 8, and the uniform part dq_j frame_size + 64 dr_j in the load's SCALAR offset field: two VALU
+    // operations a load where there were four -- 64 of ~980 per pair)
+    unsigned fthr[8], fdc[8];
     if constexpr (FRAMES) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned d = (unsigned)((H / 8) * j);
             const unsigned dq = fsp.batches == 1 ? d : __umulhi(d, fsp.magic);
-            fdr[j] = d - dq * fsp.batches;
-            fdc[j] = dq * fsp.frame_size + 64u * fdr[j];
+            const unsigned dr = d - dq * fsp.batches;
+            fthr[j] = fsp.batches - dr; // b0 + dr_j >= batches  <=>  b0 >= batches - dr_j   (dr_j < batches)
+            fdc[j] = dq * fsp.frame_size + 64u * dr;
         }
     }
     using G8 = Grp8<FRAMES>;
@@ -189,10 +193,11 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
                 const unsigned b0 = c0 - __umul24(f0, fsp.batches);
                 // (H is a multiple of 8: the same place in the cell for every j)
                 const unsigned off0 = __umul24(f0, fsp.frame_size) + 8u + b0 * 64u + ch_off + (s_ & 7u) * 2u;
+                const unsigned off8 = off0 + 8u; // (a wrap of the batch index into the next frame: that frame's 8 header bytes)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const unsigned off = off0 + fdc[j] + ((b0 + fdr[j] >= fsp.batches) ? 8u : 0u);
-                    g.set_raw(j, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0));
+                    const unsigned off = b0 >= fthr[j] ? off8 : off0;
+                    g.set_raw(j, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, off, fdc[j], 0));
                 }
                 return;
             }
