@@ -251,6 +251,16 @@ private:
     psdc_handle *h_;
 };
 
+// a record as one of `n_channels` channels, the added ones empty (psdc_pack_pad): a gather moves equal blocks, so shards whose
+// channel counts differ pad to the largest
+inline std::vector<unsigned char> pad_readout(std::span<const unsigned char> rec, uint32_t n, uint32_t n_channels)
+{
+    std::vector<unsigned char> out(psdc_readout_bytes(n, n_channels));
+    if (psdc_pack_pad(rec.data(), rec.size(), out.data(), out.size(), n_channels) < 0)
+        throw std::runtime_error(psdc_last_error(nullptr));
+    return out;
+}
+
 // PsdCascade::psd (src/psd.rs:479-543) of channel `channel` of a gathered read-out record
 inline std::pair<std::vector<float>, std::vector<Break>> psd_from_readout(std::span<const unsigned char> rec, uint32_t channel = 0,
                                                                           const MergeOpts &o = {})

@@ -139,6 +139,11 @@ int main()
         const auto [pr, brr] = psd_from_readout(rec);
         if (pr != ph || brr.size() != bh.size())
             ++bad;
+        // ... and so does the record padded to the channel count of a larger shard (psdc_pack_pad)
+        const auto rec3 = pad_readout(rec, N, 3);
+        const auto [pp, brp] = psd_from_readout(rec3);
+        if (pp != ph || brp.size() != bh.size() || !psd_from_readout(rec3, 2).first.empty())
+            ++bad;
         std::printf("caller-built windows: Hann table recognised, Hamming cascade %zu stages, record %zu bytes\n", bh.size(), rec.size());
     }
     // the batched feeder (cpp/source.hpp): a raw f32 file as stream_to_raw writes it (src/bin/stream_to_raw.rs:24-25),
