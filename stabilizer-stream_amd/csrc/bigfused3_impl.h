@@ -345,7 +345,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         for (int r = 0; r < 2; ++r) { // stage A: N/2 outputs, four per step
             const int u = tp + THREADS * r;
             float y[4];
-            hbf_four<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
+            hbf_four<HBF_MA, G::A_CE, G::A_CO, PSDK_HBF_WIDE_A != 0 && (G::XO % 4 == 0)>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
             sf[G::AE + 11 + 2 * u] = y[0];
             sf[G::AO + 11 + 2 * u] = y[1];
             sf[G::AE + 12 + 2 * u] = y[2];

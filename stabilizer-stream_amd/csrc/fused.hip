@@ -422,7 +422,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             for (int r = 0; r < 2; ++r) { // stage A: N/2 outputs, (4u .. 4u+3) -> AE/AO[11 + 2u, + 1]
                 const int u = tl + TEAM * r;
                 float y[4];
-                hbf_four<HBF_MA, G::A_CE, G::A_CO>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
+                hbf_four<HBF_MA, G::A_CE, G::A_CO, PSDK_HBF_WIDE_A != 0 && (G::XO % 4 == 0)>(sf + G::XE, sf + G::XO, 4 * u, ta, y);
                 sf[G::AE + 11 + 2 * u] = y[0];
                 sf[G::AO + 11 + 2 * u] = y[1];
                 sf[G::AE + 12 + 2 * u] = y[2];

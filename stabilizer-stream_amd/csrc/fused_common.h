@@ -11,6 +11,12 @@
 #ifndef PSDK_HBF_WIDE
 #define PSDK_HBF_WIDE 1 // stage B's shared inputs as 16-byte LDS reads (hbf_four)
 #endif
+#ifndef PSDK_XO_PAD
+#define PSDK_XO_PAD 0
+#endif
+#ifndef PSDK_HBF_WIDE_A
+#define PSDK_HBF_WIDE_A 0
+#endif
 #ifndef PSDK_DEC_PRIO
 #define PSDK_DEC_PRIO 3 // wave priority during the decimator stages (0 during the FFT)
 #endif
@@ -30,7 +36,10 @@ namespace psdk {
 template <int N, bool NOX = false>
 struct FusedDec {
     static constexpr int HX = 12, HA = 22, HB = 58;
-    static constexpr int XE = 0, XO = XE + HX / 2 + N / 2;
+    // (PSDK_XO_PAD floats between the even and the odd sample array: with 10 the two arrays sit 16 banks apart mod 32 -- the
+    // polyphase split writes lanes 2k / 2k + 1 to XE[k] / XO[k], which collide on 10 of 16 banks at the natural distance of 6 --
+    // and XO becomes 16-byte aligned, so stage A can read its shared inputs as ds_read_b128 like stage B: PSDK_HBF_WIDE_A)
+    static constexpr int XE = 0, XO = XE + HX / 2 + N / 2 + (N >= 2048 ? PSDK_XO_PAD : 0); // (the team frames have no room for it)
     static constexpr int AE = NOX ? 0 : XO + HX / 2 + N / 2, AO = AE + 12 + N / 4;
     static constexpr int BE = AO + 12 + N / 4, BO = BE + 30 + N / 8;
     static constexpr int END = BO + 30 + N / 8;
