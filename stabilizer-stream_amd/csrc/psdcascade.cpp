@@ -2073,9 +2073,17 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
     // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them, and a device that is still
     // busy with earlier rounds (when it is idle nothing is ever held back).
-    bool flush = c.submitted;
-    if (c.has_span() && (!in_place || c.fill > 0 || c.spans.size() >= h->coalesce || device_idle(h)))
-        flush = true;
+    // (hipStreamQuery is the dearest thing on this path -- tens of microseconds, against a span's ~75-100 us of kernel time: it is
+    // asked at most ONCE per call; a "busy" answer stands for the rest of the call)
+    bool flush = c.submitted, known_busy = false;
+    if (c.has_span()) {
+        if (!in_place || c.fill > 0 || c.spans.size() >= h->coalesce)
+            flush = true;
+        else if (device_idle(h))
+            flush = true;
+        else
+            known_busy = true;
+    }
     if (flush) {
         rc = advance(h);
         if (rc)
@@ -2109,7 +2117,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
             c.coalesced_seen = true;
     }
     if (h->n_channels == 1) {
-        if (c.has_span() && !c.submitted && c.spans.size() < h->coalesce && !device_idle(h))
+        if (c.has_span() && !c.submitted && c.spans.size() < h->coalesce && (known_busy || !device_idle(h)))
             return PSDC_OK; // the device is busy: the next span may share this one's round
         return advance(h);
     }
