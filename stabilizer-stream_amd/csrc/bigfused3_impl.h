@@ -85,7 +85,10 @@ __device__ __forceinline__ void window_pair3(cf (&v)[16], int tl, const g8 &lo, 
             xa *= d.ea;
             xb *= d.eb;
         }
-        v[m] = {xa, SINGLE ? 0.0f : xb}; // (SINGLE: overlap 0, one segment per pair -- fused_common.h window_pair)
+        if constexpr (SINGLE) // (overlap 0: segment b = the samples this step decimates -- fused_common.h window_pair)
+            v[m] = {xb, 0.0f};
+        else
+            v[m] = {xa, xb};
     }
 }
 
@@ -426,9 +429,9 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
         cf vv[16];
         if constexpr (EWMA) {
             if (job.ewma) {
-                dp.ea = eamp.next(job);
                 if constexpr (SINGLE == 0)
-                    dp.eb = eamp.next(job);
+                    dp.ea = eamp.next(job);
+                dp.eb = eamp.next(job);
             }
         }
         {

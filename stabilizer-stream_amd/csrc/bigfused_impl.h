@@ -643,9 +643,9 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         };
         if constexpr (EWMA) {
             if (job.ewma) {
-                dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
                 if constexpr (SINGLE == 0)
-                    dp.eb = eamp.next(job);
+                    dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
+                dp.eb = eamp.next(job);    // (SINGLE: one step per pair, segment b)
             }
         }
         // the tables of this pair in ONE batch of loads: the window and the twiddle seeds (fft_block.h) -- one

@@ -506,9 +506,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             }
             if constexpr (EWMA) {
                 if (job.ewma) {
-                    dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
                     if constexpr (SINGLE == 0)
-                        dp.eb = eamp.next(job);
+                        dp.ea = eamp.next(job); // steps job.step0 + 2 p and + 1: the pairs of a run are consecutive
+                    dp.eb = eamp.next(job);    // (SINGLE: one step per pair, segment b)
                 }
             }
             window_pair<N, DETREND, EWMA, true, SINGLE != 0>(v, tl, lo[0], lo[1], up[0], up[1], nl[0], nl[1], s_win[tl], s_win[TEAM + tl],

@@ -327,9 +327,10 @@ struct DetrendParams {
 };
 // CENTRED (Mean only): lo and up arrive with the pivot d.ob already subtracted (they are dead afterwards and
 // were rewritten in place), nl is raw.
-// SINGLE (overlap 0): only segment a = (lo, up) is transformed -- the imaginary part is an exact zero (not x_b times a zero
-// weight: an infinity in the NEXT segment's samples must not reach this one's spectrum), |Z[k]|^2 = |Z[N-k]|^2 = |X_a[k]|^2
-// and the fold 1/2 (Q[k] + Q[N-k]) of post_kernel yields the segment's power unchanged.
+// SINGLE (overlap 0): only segment b = (up, nl) is transformed -- exactly the N samples the step decimates, so a run's segments
+// and its decimated samples are the same stretch of the stream; the imaginary part is an exact zero (no other segment's samples
+// enter: an infinity next door must not reach this spectrum), |Z[k]|^2 = |Z[N-k]|^2 = |X_b[k]|^2 and the fold
+// 1/2 (Q[k] + Q[N-k]) of post_kernel yields the segment's power unchanged.  (lo is read for the decimator's history only.)
 template <int N, int DETREND, bool EWMA, bool CENTRED = false, bool SINGLE = false>
 __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &lo0, const float4 &lo1, const float4 &up0,
                                             const float4 &up1, const float4 &nl0, const float4 &nl1, const float4 &w0,
@@ -357,7 +358,10 @@ __device__ __forceinline__ void window_pair(cf (&v)[16], int tl, const float4 &l
             xa *= d.ea;
             xb *= d.eb;
         }
-        v[slot] = {xa, SINGLE ? 0.0f : xb};
+        if constexpr (SINGLE)
+            v[slot] = {xb, 0.0f};
+        else
+            v[slot] = {xa, xb};
     };
     put(0, lo0.x, up0.x, w0.x, 0);
     put(1, lo0.y, up0.y, w0.y, 1);

@@ -128,8 +128,9 @@ struct FusedBatch {
     int any_ewma; // some job has finite averaging weights
     int any_frames; // some job reads AdcDac frames (the kernels built with the frame loads run this launch)
     // overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table with overlap 0): a "pair" is ONE segment -- pair i =
-    // segment seg_a + i = samples src[N i .. N i + N), transformed with a zero imaginary part; the N samples it decimates are
-    // still src[N i + N/2 .. N i + 3N/2), so the stream is consumed exactly as with half-overlapped pairs (the SINGLE kernels).
+    // segment seg_a + i = samples src[N i + N/2 .. N i + 3N/2), transformed with a zero imaginary part: exactly the N samples the
+    // pair decimates, as ever; src points HALF A SEGMENT IN FRONT of segment seg_a (that half chunk is read for the decimator's
+    // history only), so the stream is consumed as with half-overlapped pairs (the SINGLE kernels).
     // 2 (N <= 1024): as 1, but segments 2i and 2i + 1 share ONE transform (the two-for-one of two disjoint segments); every job
     // then holds an even number of pairs and `run` is even
     int single;

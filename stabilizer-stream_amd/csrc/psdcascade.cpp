@@ -413,7 +413,9 @@ uint64_t keep_from(const Geometry &g, const StageState &s)
         return s.sink_pos;
     if (s.segs == 0)
         return 0;
-    const uint64_t back = std::max<uint64_t>(g.overlap, HBF_HALO);
+    // (overlap 0: the fused single-segment runs read half a segment in front of their first segment -- for the decimator's
+    // history registers --, so that much is carried too; it only matters for n / 2 > 288)
+    const uint64_t back = std::max<uint64_t>(std::max<uint64_t>(g.overlap, HBF_HALO), g.overlap == 0 ? g.n / 2 : 0);
     return s.dec > back ? s.dec - back : 0;
 }
 
@@ -711,8 +713,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
     const bool dbl = single && !no_double && fused_double_supported((int)h->n);
     const unsigned fstep = single ? 1 : 2;   // segments per fused "pair"
-    const uint64_t half = (uint64_t)h->n / 2; // a fused run starting at segment j decimates from sample j hop + N/2 on
-    auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + half; };
+    // a fused run starting at segment j decimates from sample j hop + N/2 on (half-overlapped pairs: the pair's new samples) -- or,
+    // overlap 0, from j N on: a single-segment step transforms exactly the samples it decimates, and its source pointer sits half
+    // a segment in front of the segment (run_src0)
+    const uint64_t half = (uint64_t)h->n / 2;
+    auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + (single ? 0 : half); };
+    auto run_src0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop - (single ? half : 0); }; // (seg >= 1 in single mode)
     // fused runs rebuild their decimator state from the 288 samples before their first new
     // sample (which sits N/2 after the run's first segment start): samples needed in front of it
     const uint64_t need_pre = HBF_HALO > half ? HBF_HALO - half : 0;
@@ -831,7 +837,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                     if (fast_ok && j_lo > 0) {
                         // fast path: the tail side gets a whole number of segment pairs and exactly their
                         // decimator outputs; the in-place side starts >= need_pre samples into the span
-                        uint64_t js = std::max<uint64_t>(j_lo, (first + need_pre + g.hop - 1) / g.hop);
+                        uint64_t js = std::max<uint64_t>(j_lo, (first + need_pre + (single ? half : 0) + g.hop - 1) / g.hop);
                         if (!single && ((js - j_lo) & 1))
                             js += 1;
                         if (js < j_hi && run_new0(js) <= first + seam && sp.len >= seam) {
@@ -983,14 +989,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             uint64_t np = (fast_ok && nx && fs + fstep <= sp.seg_b && (!framed || (!single && fused_frames_supported((int)h->n))))
                               ? (sp.seg_b - fs) / fstep : 0;
             if (single && np) {
-                // a single-segment "pair" decimates the N/2 samples behind its segment too: they must be this span's share
-                // (the last segment of a span -- of a round -- is left to the generic kernels with its half chunk)
-                const uint64_t lim = 8 * sp.m_b;
-                np = run_new0(fs) + h->n <= lim ? std::min<uint64_t>(np, (lim - run_new0(fs)) / h->n) : 0;
+                if (run_src0(fs) < sp.src_base) // (the half chunk in front of the first segment is not in this source)
+                    np = 0;
                 if (dbl)
-                    np &= ~(uint64_t)1; // (the odd segment goes with the span's last one: generic kernels)
+                    np &= ~(uint64_t)1; // (an odd last segment goes to the generic kernels)
             }
-            const uint64_t fofs = (uint64_t)g.hop * fs - sp.src_base; // samples of this span in front of the pairs
+            const uint64_t fofs = np ? run_src0(fs) - sp.src_base : 0; // samples of this span in front of the pairs' source
             const float *fsrc = framed ? nullptr : sp.src + fofs;
             const uint64_t mf0 = run_new0(fs) / 8, mf1 = mf0 + (h->n / 8) * np;
             const bool aligned = framed ? (fofs & 3u) == 0 : (reinterpret_cast<uintptr_t>(fsrc) & 15u) == 0;

@@ -247,7 +247,7 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
             const int tag = fr ? job.fch * 16 : (int)(bits_of(job.src) >> 24);
             // absolute index of the job's first sample (segment seg_a starts there)
             const uint64_t a0 = fr ? (frame_ident(*fs, job.fch, job.s_off, 8, "fused (frames)") & 0xFFFFFFu) : (bits_of(job.src) & 0xFFFFFFu);
-            if (a0 % (unsigned)hop)
+            if ((a0 + (b.single ? n / 2 : 0)) % (unsigned)hop)
                 error("fused job %d: starts at sample %llu, not on a segment boundary", ji, (unsigned long long)a0);
             auto sample_ok = [&](long long j, int width) { // sample j of the job (j may be negative: the warm-up) is sample a0 + j
                 if (fr)
@@ -287,7 +287,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
                                 error("fused job %d pair %lld: sample at offset %lld is not sample %lld of stream tag %d", ji, p, j,
                                       (long long)a0 + j, tag);
                         }
-                        const uint64_t s0 = (a0 + (uint64_t)n * p) / (unsigned)hop;
+                        // (single: the segment is the pair's new samples, half a chunk behind the source pointer)
+                        const uint64_t s0 = (a0 + (uint64_t)n * p + (b.single ? n / 2 : 0)) / (unsigned)hop;
                         mark(world().seg, tag, s0);
                         if (!b.single)
                             mark(world().seg, tag, s0 + 1);
