@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--channels-per-gpu", type=int, default=None, help="default 1 at --gpus 1, 8 at --gpus > 1 (config 4)")
     ap.add_argument("--detrend", default="none")
     ap.add_argument("--window", default="hann", choices=["hann", "rectangular", "hamming"],
-                    help="hann (the configs'), rectangular (overlap 0: generic kernels) or a caller-built Hamming table with overlap N/2")
+                    help="hann (the configs'), rectangular (overlap 0: the fused kernels, two disjoint segments per transform) or a caller-built Hamming table with overlap N/2")
     ap.add_argument("--coalesce", type=int, default=None,
                     help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 8)")
     ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")

@@ -125,11 +125,13 @@ typedef struct psdc_profile {
  * Which kernels run: the single-pass fused kernels (stream read once: detrend +
  * window + FFT + |X|^2 + /8 decimator in one launch) exist for n = 256 ... 16384 (powers of two) and every window
  * whose overlap is n / 2 -- the HANN window (what the reference's binaries and BASELINE configs use) and caller-built
- * tables with that overlap; they read the table and assume only the hop.  The
- * rectangular window, caller-built windows of another overlap, n < 256 and sizes that are not powers of two take the generic
+ * tables with that overlap; they read the table and assume only the hop -- or 0: Window::rectangular() and caller-built
+ * tables without overlap, where two disjoint segments share one transform (faster than the Hann path: half the FFT work).
+ * Caller-built windows of another overlap, n < 256 and sizes that are not powers of two take the generic
  * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about a third of the rate;
  * sizes that are not powers of two evaluate the DFT in chirp-z form on a power-of-two transform of at
- * least twice the length: two such transforms per segment pair). */
+ * least twice the length: two such transforms per segment pair); the powers of two 32768 ... 131072 a slow path whose FFT
+ * passes go through device memory (~20 GS/s). */
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
 
 /* The same with a caller-supplied `Window<N>` -- the struct is public with public fields `win`, `power`,
