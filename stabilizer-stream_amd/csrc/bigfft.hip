@@ -6,11 +6,13 @@
 // same semantics and the same 1e-5 parity (a chunk of up to a few hundred pairs per pass launch, so that the passes are HBM-bound
 // and not launch-bound): the segments of a job are processed pair by pair (two-for-one, as everywhere:
 // z = x_a + i x_b, sum of the two segments' power = 1/2 (|Z[k]|^2 + |Z[N-k]|^2), folded by post_kernel) through a Stockham
-// autosort FFT whose passes go through global memory -- radix-4 passes, one radix-2 pass when log2 N is odd --, natural-order
+// autosort FFT whose passes go through global memory -- radix-16 passes and one of radix 8 or 2 for what is left --, natural-order
 // output, |Z|^2 accumulated into the job's ONE partial row.  The decimator (hbf_dec8_kernel) and everything else are size-
-// independent already.  ~11 launches per chunk and ~(8 + 16 log4 N) bytes of traffic per sample: 17-23 GS/s measured (N = 131072 ...
+// independent already.  ~7 launches per chunk and ~(8 + 16 log16 N) bytes of traffic per sample: 17-23 GS/s measured (N = 131072 ...
 // 32768), not hundreds.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "fft_core.h"
 #include "kernels.h"
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_load_kernel(const SegJo
     }
 }
 
-// One Stockham pass over every pair of the chunk: sub-transform length ns, stride s (ns * s = n).  Butterfly t of a pair:
-// p = t / s, q = t % s; inputs x[q + s (p + r m)], outputs y[q + s (R p + r)] times W_ns^(r p) (forward DFT: -i on the odd terms).
+// One Stockham pass of radix R over every pair of the chunk: sub-transform length ns, stride s (ns * s = n).  Butterfly t of a pair:
+// p = t / s, q = t % s; inputs x[q + s (p + r m)], m = ns / R; outputs y[q + s (R p + r)] = W_ns^(r p) DFT_R(inputs)[r].
 // tw[j] = W_n^j, so W_ns^(r p) = tw[r p s mod n].
 template <int R>
 __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_pass_kernel(const cf *__restrict__ x, cf *__restrict__ y,
@@ -115,39 +117,47 @@ __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_pass_kernel(const cf *_
         return;
     const int pair = (int)(g / per), t = (int)(g % per);
     const int p = t / s, q = t % s, m = ns / R;
-    const cf *xi = x + (size_t)pair * n;
-    cf *yo = y + (size_t)pair * n;
-    if constexpr (R == 4) {
-        const cf a = xi[q + s * p], b = xi[q + s * (p + m)], c = xi[q + s * (p + 2 * m)], d = xi[q + s * (p + 3 * m)];
-        const cf apc = {a.re + c.re, a.im + c.im}, amc = {a.re - c.re, a.im - c.im};
-        const cf bpd = {b.re + d.re, b.im + d.im};
-        const cf jbmd = {b.im - d.im, -(b.re - d.re)}; // -i (b - d)
-        const int k = (int)(((long long)p * s) % n);
-        const cf w1 = tw[k], w2 = tw[(2 * k) % n], w3 = tw[(int)((3LL * k) % n)];
-        yo[q + s * (4 * p)] = {apc.re + bpd.re, apc.im + bpd.im};
-        yo[q + s * (4 * p + 1)] = cmul(w1, cf{amc.re + jbmd.re, amc.im + jbmd.im});
-        yo[q + s * (4 * p + 2)] = cmul(w2, cf{apc.re - bpd.re, apc.im - bpd.im});
-        yo[q + s * (4 * p + 3)] = cmul(w3, cf{amc.re - jbmd.re, amc.im - jbmd.im});
-    } else {
-        const cf a = xi[q + s * p], b = xi[q + s * (p + m)];
-        const cf w1 = tw[(int)(((long long)p * s) % n)];
-        yo[q + s * (2 * p)] = {a.re + b.re, a.im + b.im};
-        yo[q + s * (2 * p + 1)] = cmul(w1, cf{a.re - b.re, a.im - b.im});
-    }
+    const cf *xi = x + (size_t)pair * n + q + (size_t)s * p;
+    cf *yo = y + (size_t)pair * n + q + (size_t)s * R * p;
+    cf v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        v[r] = xi[(size_t)s * m * r];
+    Dft<R>::run(v); // natural-order outputs (fft_core.h)
+    const int k = (int)(((long long)p * s) % n); // W_ns^p = tw[p s]
+    yo[0] = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        yo[(size_t)s * r] = cmul(tw[(int)(((long long)k * r) % n)], v[r]);
 }
 
-// |Z|^2 of the chunk's pairs into the job's partial row (natural bin order; post_kernel folds k with N - k)
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_power_kernel(const cf *__restrict__ z, float *__restrict__ partial, int n,
-                                                                      int npairs, int accumulate)
+// |Z|^2 of the chunk's pairs into the job's partial row (natural bin order; post_kernel folds k with N - k), in two steps with a
+// fixed order of additions (bit-reproducible, like the fused paths): groups of 16 pairs are summed per bin into the frame the last
+// pass left free, then the groups' sums are added to the row in group order.
+constexpr int BIGFFT_PGROUP = 16;
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_power_kernel(const cf *__restrict__ z, float *__restrict__ gsum, int n, int npairs)
+{
+    const int k = blockIdx.x * BIGFFT_THREADS + threadIdx.x;
+    const int grp = blockIdx.y;
+    if (k >= n)
+        return;
+    const int q0 = grp * BIGFFT_PGROUP, q1 = min(npairs, q0 + BIGFFT_PGROUP);
+    float acc = 0.0f;
+    for (int q = q0; q < q1; ++q) {
+        const cf v = z[(size_t)q * n + k];
+        acc = fmaf(v.re, v.re, fmaf(v.im, v.im, acc));
+    }
+    gsum[(size_t)grp * n + k] = acc;
+}
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_fold_kernel(const float *__restrict__ gsum, float *__restrict__ partial, int n,
+                                                                     int groups, int accumulate)
 {
     const int k = blockIdx.x * BIGFFT_THREADS + threadIdx.x;
     if (k >= n)
         return;
     float acc = accumulate ? partial[k] : 0.0f;
-    for (int q = 0; q < npairs; ++q) {
-        const cf v = z[(size_t)q * n + k];
-        acc = fmaf(v.re, v.re, fmaf(v.im, v.im, acc));
-    }
+    for (int g = 0; g < groups; ++g)
+        acc += gsum[(size_t)g * n + k];
     partial[k] = acc;
 }
 
@@ -166,24 +176,30 @@ hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const 
             const int np = std::min(chunk_max, pairs - p0);
             hipLaunchKernelGGL(bigfft_load_kernel, dim3(np), dim3(BIGFFT_THREADS), 0, s, job, b.hop, b.detrend, n, win, buf[0], p0);
             int cur = 0, ns = n, st = 1;
-            while (ns > 1) {
-                if (ns % 4 == 0) {
-                    const long long work = (long long)(n / 4) * np;
-                    hipLaunchKernelGGL(bigfft_pass_kernel<4>, dim3((unsigned)((work + BIGFFT_THREADS - 1) / BIGFFT_THREADS)),
-                                       dim3(BIGFFT_THREADS), 0, s, buf[cur], buf[cur ^ 1], tw, n, ns, st, np);
-                    ns /= 4;
-                    st *= 4;
-                } else {
-                    const long long work = (long long)(n / 2) * np;
-                    hipLaunchKernelGGL(bigfft_pass_kernel<2>, dim3((unsigned)((work + BIGFFT_THREADS - 1) / BIGFFT_THREADS)),
-                                       dim3(BIGFFT_THREADS), 0, s, buf[cur], buf[cur ^ 1], tw, n, ns, st, np);
-                    ns /= 2;
-                    st *= 2;
-                }
+            auto pass = [&](auto radix) {
+                constexpr int R = decltype(radix)::value;
+                const long long work = (long long)(n / R) * np;
+                hipLaunchKernelGGL(bigfft_pass_kernel<R>, dim3((unsigned)((work + BIGFFT_THREADS - 1) / BIGFFT_THREADS)), dim3(BIGFFT_THREADS), 0,
+                                   s, buf[cur], buf[cur ^ 1], tw, n, ns, st, np);
+                ns /= R;
+                st *= R;
                 cur ^= 1;
+            };
+            while (ns > 1) { // radix-16 passes, then whatever is left (32768 = 16^3 x 8, 65536 = 16^4, 131072 = 16^4 x 2)
+                if (ns % 16 == 0)
+                    pass(std::integral_constant<int, 16>{});
+                else if (ns % 8 == 0)
+                    pass(std::integral_constant<int, 8>{});
+                else if (ns % 4 == 0)
+                    pass(std::integral_constant<int, 4>{});
+                else
+                    pass(std::integral_constant<int, 2>{});
             }
-            hipLaunchKernelGGL(bigfft_power_kernel, dim3((n + BIGFFT_THREADS - 1) / BIGFFT_THREADS), dim3(BIGFFT_THREADS), 0, s, buf[cur],
-                               job.partial, n, np, p0 > 0 ? 1 : 0);
+            const unsigned kb = (unsigned)((n + BIGFFT_THREADS - 1) / BIGFFT_THREADS);
+            const int groups = (np + BIGFFT_PGROUP - 1) / BIGFFT_PGROUP;
+            float *gsum = reinterpret_cast<float *>(buf[cur ^ 1]); // (groups * n floats <= np * n complex elements: it fits)
+            hipLaunchKernelGGL(bigfft_power_kernel, dim3(kb, (unsigned)groups), dim3(BIGFFT_THREADS), 0, s, buf[cur], gsum, n, np);
+            hipLaunchKernelGGL(bigfft_fold_kernel, dim3(kb), dim3(BIGFFT_THREADS), 0, s, gsum, job.partial, n, groups, p0 > 0 ? 1 : 0);
         }
     }
     return hipGetLastError();
