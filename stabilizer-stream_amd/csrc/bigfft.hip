@@ -2,17 +2,15 @@
 //
 // The reference plans ANY length (`FftPlanner::plan_fft_forward(N)`, src/psd.rs:417-418); what it can actually run is bounded
 // by its own `[Complex<f32>; N]` / `[f32; N]` stack frames (src/psd.rs:75-80, 457-458: a few hundred KiB per call at N = 65536
-// on a 2 MiB thread stack).  No BASELINE config uses these sizes; this is the slow, simple path that makes them RUN with the
-// same semantics and the same 1e-5 parity (a chunk of up to a few hundred pairs per pass launch, so that the passes are HBM-bound
-// and not launch-bound): the segments of a job are processed pair by pair (two-for-one, as everywhere:
-// z = x_a + i x_b, sum of the two segments' power = 1/2 (|Z[k]|^2 + |Z[N-k]|^2), folded by post_kernel) through a Stockham
-// autosort FFT whose passes go through global memory -- radix-16 passes and one of radix 8 or 2 for what is left --, natural-order
-// output, |Z|^2 accumulated into the job's ONE partial row.  The decimator (hbf_dec8_kernel) and everything else are size-
-// independent already.  ~7 launches per chunk and ~(8 + 16 log16 N) bytes of traffic per sample: 17-23 GS/s measured (N = 131072 ...
-// 32768), not hundreds.
+// on a 2 MiB thread stack).  No BASELINE config uses these sizes; this path makes them RUN with the same semantics and the same
+// 1e-5 parity: the segments of a job are processed pair by pair (two-for-one, as everywhere: z = x_a + i x_b, sum of the two
+// segments' power = 1/2 (|Z[k]|^2 + |Z[N-k]|^2), folded by post_kernel) through a four-step transform N = N1 x 256 with ONE
+// intermediate frame in global memory (a chunk of up to a thousand pairs per launch), natural-order output, |Z|^2 accumulated
+// into the job's ONE partial row.  The decimator (hbf_dec8_kernel) and everything else are size-independent already.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 #include "fft_core.h"
 #include "kernels.h"
@@ -33,175 +31,353 @@ __device__ __forceinline__ float big_ewma_amp(const SegJob &job, int step)
     return (float)exp2(0.5 * (double)na * job.log2_gamma);
 }
 
-// pair q of the chunk (one workgroup): detrend (src/psd.rs:75-113) + window + EWMA amplitude of segments (a, b) into z[q][0..N)
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_load_kernel(const SegJob job, int hop, int detrend, int n,
-                                                                     const float *__restrict__ win, cf *__restrict__ z, int pair0)
+// ---- the four-step path: N = N1 x 256, two kernels a pair, the transposition done by which index each kernel walks ----
+//
+// Sample n = 256 n1 + n2, bin k = k1 + N1 k2:  Z[k] = sum_n2 W_256^(n2 k2) [ W_N^(n2 k1) sum_n1 z[256 n1 + n2] W_N1^(n1 k1) ].
+// bigfft_col_kernel: a workgroup takes C adjacent columns n2 of one pair -- detrend, window and EWMA amplitude at the loads (C
+// consecutive samples a row: 64 or 128 bytes), the first radix-16 pass over n1 straight from those registers, the rest of the
+// length-N1 transform through one LDS frame [n1][c] -- and writes its part of T[n2 / 16][k1][n2 % 16], one contiguous run.
+// bigfft_row_kernel: a workgroup takes sixteen rows k1 for a group of sixteen pairs: each lane keeps the sixteen W_N^(n2 k1) of
+// its elements in registers for the whole group, reads its row elements (128-byte runs), does the 256-point transform over n2 as
+// radix 16 x 16 with the one exchange inside its own 16-lane team, and accumulates |Z|^2 over the group in registers.
+// ~20 bytes of traffic per sample (4 + 4 read, 8 written, 8 read; the transposed frame T never leaves the Infinity Cache at the
+// smaller chunks) where the pass-by-pass path above moved ~(8 + 16 log16 N).
+constexpr int BIG_N2 = 256;
+constexpr int BIGFFT_PGROUP = 16;  // pairs whose |Z|^2 one row-kernel workgroup sums in registers
+constexpr int BIG_MAX_PIECES = 32; // (job, pair range) pieces a chunk may hold: every job of a round shares the chunk's launches
+struct BigPiece {
+    SegJob job;
+    int pair0, npairs; // pairs [pair0, pair0 + npairs) of the job ...
+    int tpair0;        // ... sit at pairs [tpair0, ...) of the chunk's frame T,
+    int group0;        // their groups of BIGFFT_PGROUP at gsum[group0 ...)
+    int accumulate;    // 0: the job's first piece (the partial row is written, not added to)
+    int pad;
+};
+struct BigChunk {
+    int npieces, npairs, ngroups, pad;
+    BigPiece pieces[BIG_MAX_PIECES];
+};
+__device__ __forceinline__ int big_piece_of_pair(const BigChunk &ch, int tq)
 {
-    __shared__ double red[2 * BIGFFT_THREADS / 64];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int la = 2 * (pair0 + q); // local index of segment a
+    int pi = 0;
+    while (pi + 1 < ch.npieces && tq >= ch.pieces[pi + 1].tpair0)
+        ++pi;
+    return pi;
+}
+constexpr int BIG_RSTRIDE = 272; // LDS row stride of the row kernel: element 16 p + r of a row sits at 17 p + r
+
+#ifndef PSDK_BIG_COLPAD
+#define PSDK_BIG_COLPAD 1
+#endif
+template <int N1, int C>
+struct ColFrame {
+    // sixteen elements of padding per sixteen rows: the first pass's stores of a wavefront (rows 16 apart) spread over the banks.
+    // (Without it the frame is 32 KiB and five workgroups fit a CU instead of four: measured -2 ... -4 %.)
+    static constexpr int ELEMS = N1 * C + (PSDK_BIG_COLPAD ? (N1 / 16) * 16 : 0);
+    static __device__ __forceinline__ int at(int n1, int c) { return n1 * C + c + (PSDK_BIG_COLPAD ? (n1 >> 4) * 16 : 0); }
+};
+
+// One in-LDS Stockham pass of radix R over the N1 index of every column of the tile (ns, s as in bigfft_pass_kernel); the LAST pass
+// hands its outputs (k1 natural) to `out(k1, c, value)` instead of storing them back.
+template <int N1, int C, int R, int NS, int S, bool LAST, typename Out>
+__device__ __forceinline__ void col_lds_pass(cf *frame, const cf *__restrict__ tw, int n, int tid, Out out)
+{
+    using F = ColFrame<N1, C>;
+    constexpr int NB = (N1 / R) * C, PER = NB / BIGFFT_THREADS, M = NS / R;
+    static_assert(NB % BIGFFT_THREADS == 0, "butterflies per thread");
+    cf v[PER][R];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = tid + i * BIGFFT_THREADS, c = b % C, t = b / C;
+        const int p = t / S, q = t % S;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[i][r] = frame[F::at(q + S * (p + r * M), c)];
+    }
+    if (!LAST)
+        __syncthreads(); // (in place: every read before any store)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = tid + i * BIGFFT_THREADS, c = b % C, t = b / C;
+        const int p = t / S, q = t % S;
+        Dft<R>::run(v[i]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            cf y = v[i][r];
+            if (NS > R && r > 0)
+                y = cmul(tw[(n / NS) * r * p], y); // W_NS^(r p)
+            const int o = q + S * (R * p + r);
+            if constexpr (LAST)
+                out(o, c, y);
+            else
+                frame[F::at(o, c)] = y;
+        }
+    }
+    if (!LAST)
+        __syncthreads();
+}
+
+template <int N1, int C>
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_col_kernel(const BigChunk ch, int hop, int detrend, const float *__restrict__ win,
+                                                                    const cf *__restrict__ tw, const double *__restrict__ means,
+                                                                    cf *__restrict__ T)
+{
+    using F = ColFrame<N1, C>;
+    constexpr int n = N1 * BIG_N2, M = N1 / 16, NB = M * C, PER = NB / BIGFFT_THREADS;
+    static_assert(NB % BIGFFT_THREADS == 0, "butterflies per thread");
+    __shared__ cf frame[F::ELEMS];
+    // The workgroups of one pair (and of its neighbours, which share half their samples) on ONE XCD, whose L2 then holds the lines
+    // they share: the dispatcher deals consecutive workgroup ids round the eight XCDs.
+    const int tid = threadIdx.x, tiles = BIG_N2 / C;
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+    const unsigned item = total % 8 == 0 ? (lin % 8) * (total / 8) + lin / 8 : lin;
+    const int c0 = (int)(item % tiles) * C, pq = (int)(item / tiles); // pq: the pair's place in the chunk
+    const BigPiece &pc = ch.pieces[big_piece_of_pair(ch, pq)];
+    const SegJob &job = pc.job;
+    const int la = 2 * (pc.pair0 + pq - pc.tpair0); // local index of segment a
     const bool act_b = la + 1 < job.nseg;
     const float *xa = job.src + ((job.seg0 + la) * (long long)hop - job.src_base);
-    const float *xb = xa + hop;
+    const float *xb = act_b ? xa + hop : xa; // (an odd last segment: b reads a's samples and is zeroed below)
     float oa = 0.0f, ob = 0.0f;
     double ma = 0.0, mb = 0.0;
     slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
     if (detrend == 1) { // Midpoint :87-93
         oa = xa[n / 2];
-        ob = act_b ? xb[n / 2] : 0.0f;
-    } else if (detrend == 2) { // Span :94-102, the ramp as o + j (s_hi + s_lo) (fft_core.h span_slope)
+        ob = xb[n / 2];
+    } else if (detrend == 2) { // Span :94-102
         oa = xa[0];
         sa = span_slope(oa, xa[n - 1], n);
-        if (act_b) {
-            ob = xb[0];
-            sb = span_slope(ob, xb[n - 1], n);
-        }
-    } else if (detrend == 3) { // Mean :103-109: the sums in f64 (the reference's sequential f32 sum is what the f32 oracle keeps)
-        double pa = 0.0, pb = 0.0;
-        for (int j = tid; j < n; j += BIGFFT_THREADS) {
-            pa += (double)xa[j];
-            if (act_b)
-                pb += (double)xb[j];
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            pa += __shfl_xor(pa, o);
-            pb += __shfl_xor(pb, o);
-        }
-        if ((tid & 63) == 0) {
-            red[2 * (tid >> 6)] = pa;
-            red[2 * (tid >> 6) + 1] = pb;
-        }
-        __syncthreads();
-        pa = pb = 0.0;
-        for (int w = 0; w < BIGFFT_THREADS / 64; ++w) {
-            pa += red[2 * w];
-            pb += red[2 * w + 1];
-        }
-        ma = pa / (double)n;
-        mb = pb / (double)n;
+        ob = xb[0];
+        sb = span_slope(ob, xb[n - 1], n);
+    } else if (detrend == 3) { // Mean :103-109 (bigfft_mean_kernel)
+        ma = means[2 * pq];
+        mb = means[2 * pq + 1];
     }
     float ampa = 1.0f, ampb = 1.0f;
     if (job.ewma) {
         ampa = big_ewma_amp(job, job.step0 + la);
         ampb = big_ewma_amp(job, job.step0 + la + 1);
     }
-    cf *out = z + (size_t)q * n;
-    for (int j = tid; j < n; j += BIGFFT_THREADS) {
-        float a = xa[j], b = act_b ? xb[j] : 0.0f;
-        if (detrend == 1) {
-            a -= oa;
-            b -= ob;
-        } else if (detrend == 2) {
-            const float f = (float)j;
-            a = fmaf(-f, sa.lo, fmaf(-f, sa.hi, a - oa));
-            b = fmaf(-f, sb.lo, fmaf(-f, sb.hi, b - ob));
-        } else if (detrend == 3) {
-            a = (float)((double)a - ma);
-            b = (float)((double)b - mb);
+    if (!act_b)
+        ampb = 0.0f;
+    // pass 1 (radix 16, sub-transform length N1, stride 1): butterfly p of column c takes rows p + M r
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = tid + i * BIGFFT_THREADS, c = b % C, p = b / C;
+        cf v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = BIG_N2 * (p + M * r) + c0 + c;
+            float a = xa[j], bb = xb[j];
+            if (detrend == 1) {
+                a -= oa;
+                bb -= ob;
+            } else if (detrend == 2) {
+                const float f = (float)j;
+                a = fmaf(-f, sa.lo, fmaf(-f, sa.hi, a - oa));
+                bb = fmaf(-f, sb.lo, fmaf(-f, sb.hi, bb - ob));
+            } else if (detrend == 3) {
+                a = (float)((double)a - ma);
+                bb = (float)((double)bb - mb);
+            }
+            const float w = win[j];
+            v[r] = {a * w * ampa, act_b ? bb * w * ampb : 0.0f};
         }
-        const float w = win[j];
-        out[j] = {a * w * ampa, act_b ? b * w * ampb : 0.0f};
+        Dft<16>::run(v);
+        frame[F::at(16 * p, c)] = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            frame[F::at(16 * p + r, c)] = cmul(tw[BIG_N2 * r * p], v[r]); // W_N1^(r p)
+    }
+    __syncthreads();
+    // T[pair][n2 / 16][k1][n2 % 16]: this workgroup's outputs are ONE contiguous run of N1 x 128 bytes per sixteen columns
+    cf *Tp = T + (size_t)pq * n + (size_t)(c0 >> 4) * (N1 * 16);
+    auto store = [&](int k1, int c, cf y) { Tp[(c >> 4) * (N1 * 16) + k1 * 16 + (c & 15)] = y; };
+    if constexpr (N1 == 128)
+        col_lds_pass<N1, C, 8, 8, 16, true>(frame, tw, n, tid, store);
+    else if constexpr (N1 == 256)
+        col_lds_pass<N1, C, 16, 16, 16, true>(frame, tw, n, tid, store);
+    else {
+        static_assert(N1 == 512, "N1");
+        col_lds_pass<N1, C, 16, 32, 16, false>(frame, tw, n, tid, store);
+        col_lds_pass<N1, C, 2, 2, 256, true>(frame, tw, n, tid, store);
     }
 }
 
-// One Stockham pass of radix R over every pair of the chunk: sub-transform length ns, stride s (ns * s = n).  Butterfly t of a pair:
-// p = t / s, q = t % s; inputs x[q + s (p + r m)], m = ns / R; outputs y[q + s (R p + r)] = W_ns^(r p) DFT_R(inputs)[r].
-// tw[j] = W_n^j, so W_ns^(r p) = tw[r p s mod n].
-template <int R>
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_pass_kernel(const cf *__restrict__ x, cf *__restrict__ y,
-                                                                     const cf *__restrict__ tw, int n, int ns, int s, int npairs)
+// the f64 means of the chunk's segments (detrend Mean): one workgroup a segment, means[2 pq + (0 | 1)]
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_mean_kernel(const BigChunk ch, int hop, int n, double *__restrict__ means)
 {
-    const long long g = (long long)blockIdx.x * BIGFFT_THREADS + threadIdx.x;
-    const int per = n / R;
-    if (g >= (long long)per * npairs)
+    __shared__ double red[BIGFFT_THREADS / 64];
+    const int tid = threadIdx.x, pq = blockIdx.x >> 1;
+    const BigPiece &pc = ch.pieces[big_piece_of_pair(ch, pq)];
+    const SegJob &job = pc.job;
+    const int l = 2 * (pc.pair0 + pq - pc.tpair0) + (blockIdx.x & 1);
+    if (l >= job.nseg) {
+        if (tid == 0)
+            means[blockIdx.x] = 0.0;
         return;
-    const int pair = (int)(g / per), t = (int)(g % per);
-    const int p = t / s, q = t % s, m = ns / R;
-    const cf *xi = x + (size_t)pair * n + q + (size_t)s * p;
-    cf *yo = y + (size_t)pair * n + q + (size_t)s * R * p;
-    cf v[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        v[r] = xi[(size_t)s * m * r];
-    Dft<R>::run(v); // natural-order outputs (fft_core.h)
-    const int k = (int)(((long long)p * s) % n); // W_ns^p = tw[p s]
-    yo[0] = v[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r)
-        yo[(size_t)s * r] = cmul(tw[(int)(((long long)k * r) % n)], v[r]);
+    }
+    const float *x = job.src + ((job.seg0 + l) * (long long)hop - job.src_base);
+    double s = 0.0;
+    for (int j = tid; j < n; j += BIGFFT_THREADS)
+        s += (double)x[j];
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_xor(s, o);
+    if ((tid & 63) == 0)
+        red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BIGFFT_THREADS / 64; ++w)
+            t += red[w];
+        means[blockIdx.x] = t / (double)n;
+    }
 }
 
-// |Z|^2 of the chunk's pairs into the job's partial row (natural bin order; post_kernel folds k with N - k), in two steps with a
-// fixed order of additions (bit-reproducible, like the fused paths): groups of 16 pairs are summed per bin into the frame the last
-// pass left free, then the groups' sums are added to the row in group order.
-constexpr int BIGFFT_PGROUP = 16;
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_power_kernel(const cf *__restrict__ z, float *__restrict__ gsum, int n, int npairs)
+// rows k1 = 16 blockIdx.x ... + 15 of the pairs of group blockIdx.y (up to BIGFFT_PGROUP pairs of ONE piece): gsum[group][256 k1 + k2]
+// = sum over the group of |Z[k1 + N1 k2]|^2, the additions in pair order
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_row_kernel(const BigChunk ch, const cf *__restrict__ T, const cf *__restrict__ tw,
+                                                                    float *__restrict__ gsum, int n, int n1)
 {
-    const int k = blockIdx.x * BIGFFT_THREADS + threadIdx.x;
-    const int grp = blockIdx.y;
-    if (k >= n)
-        return;
-    const int q0 = grp * BIGFFT_PGROUP, q1 = min(npairs, q0 + BIGFFT_PGROUP);
-    float acc = 0.0f;
+    __shared__ cf buf[16 * BIG_RSTRIDE];
+    __shared__ cf w256[256];
+    const int tid = threadIdx.x, p = tid & 15, rho = tid >> 4;
+    const int k1 = 16 * blockIdx.x + rho, grp = blockIdx.y;
+    w256[tid] = tw[n1 * (tid >> 4) * (tid & 15)]; // [r][p] = W_256^(r p)
+    cf twd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        twd[r] = tw[k1 * (p + 16 * r)]; // W_N^(n2 k1), n2 = p + 16 r  (k1 n2 < N1 256 = N)
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc[r] = 0.0f;
+    __syncthreads();
+    int pi = 0;
+    while (pi + 1 < ch.npieces && grp >= ch.pieces[pi + 1].group0)
+        ++pi;
+    const BigPiece &pc = ch.pieces[pi];
+    const int q0 = pc.tpair0 + (grp - pc.group0) * BIGFFT_PGROUP, q1 = min(pc.tpair0 + pc.npairs, q0 + BIGFFT_PGROUP);
+    cf *mine = buf + rho * BIG_RSTRIDE;
+    const cf *row = T + (size_t)q0 * n + (size_t)k1 * 16 + p; // element n2 = p + 16 r: T[pair][r][k1][p], the workgroup's 16 rows 2 KiB runs
+    const size_t rs = (size_t)n1 * 16;
+    cf nx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        nx[r] = row[rs * r];
     for (int q = q0; q < q1; ++q) {
-        const cf v = z[(size_t)q * n + k];
-        acc = fmaf(v.re, v.re, fmaf(v.im, v.im, acc));
+        cf v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r] = cmul(nx[r], twd[r]);
+        if (q + 1 < q1) {
+            row += n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                nx[r] = row[rs * r];
+        }
+        Dft<16>::run(v); // pass 1 (sub-transform length 256, stride 1): outputs element 16 p + r, times W_256^(r p)
+        mine[17 * p] = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            mine[17 * p + r] = cmul(w256[16 * r + p], v[r]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r] = mine[17 * r + p]; // pass 2 (length 16, stride 16): butterfly p takes elements p + 16 r
+        __syncthreads();
+        Dft<16>::run(v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[r] = fmaf(v[r].re, v[r].re, fmaf(v[r].im, v[r].im, acc[r])); // k2 = p + 16 r
     }
-    gsum[(size_t)grp * n + k] = acc;
-}
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_fold_kernel(const float *__restrict__ gsum, float *__restrict__ partial, int n,
-                                                                     int groups, int accumulate)
-{
-    const int k = blockIdx.x * BIGFFT_THREADS + threadIdx.x;
-    if (k >= n)
-        return;
-    float acc = accumulate ? partial[k] : 0.0f;
-    for (int g = 0; g < groups; ++g)
-        acc += gsum[(size_t)g * n + k];
-    partial[k] = acc;
+    float *g = gsum + (size_t)grp * n + (size_t)k1 * BIG_N2 + p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        g[16 * r] = acc[r];
 }
 
-hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, hipStream_t s)
+// the groups' sums of piece blockIdx.z into its job's partial row, natural bin order k = k1 + N1 k2 (post_kernel folds k with N - k):
+// 16 x 16 tiles transposed through LDS, the groups added in their order (bit-reproducible, like the fused paths)
+__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_fold_kernel(const BigChunk ch, const float *__restrict__ gsum, int n, int n1)
 {
-    if (!bigfft_size(n) || !scratch || scratch_elems < 2 * (size_t)n)
+    __shared__ float tile[16][17];
+    const BigPiece &pc = ch.pieces[blockIdx.z];
+    const int groups = (pc.npairs + BIGFFT_PGROUP - 1) / BIGFFT_PGROUP;
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int k2_0 = 16 * blockIdx.x, k1_0 = 16 * blockIdx.y;
+    const float *g = gsum + (size_t)pc.group0 * n + (size_t)(k1_0 + y) * BIG_N2 + k2_0 + x;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < groups; ++i)
+        acc += g[(size_t)i * n];
+    tile[y][x] = acc;
+    __syncthreads();
+    float *dst = pc.job.partial + (size_t)(k1_0 + x) + (size_t)n1 * (k2_0 + y);
+    *dst = (pc.accumulate ? *dst : 0.0f) + tile[x][y];
+}
+
+hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, int chunk_limit,
+                            hipStream_t s)
+{
+    // scratch (in complex elements): T [chunk][n] | gsum [chunk / 16 + BIG_MAX_PIECES][n] f32 | means [2 chunk] f64
+    const int n1 = n / BIG_N2;
+    const size_t fixed = (size_t)BIG_MAX_PIECES * n / 2 + 64;
+    if (!bigfft_size(n) || !scratch || scratch_elems < fixed + 2 * ((size_t)n + n / 32 + 2))
         return hipErrorInvalidValue;
-    const int chunk_max = (int)std::min<size_t>(1024, scratch_elems / (2 * (size_t)n));
-    cf *buf[2] = {scratch, scratch + (size_t)chunk_max * n};
+    int chunk_max = (int)std::min<size_t>(1024, (scratch_elems - fixed) / ((size_t)n + n / 32 + 2));
+    if (chunk_limit > 0)
+        chunk_max = std::min(chunk_max, chunk_limit);
+    chunk_max = chunk_max >= BIGFFT_PGROUP ? chunk_max / BIGFFT_PGROUP * BIGFFT_PGROUP : chunk_max;
+    cf *T = scratch;
+    float *gsum = reinterpret_cast<float *>(scratch + (size_t)chunk_max * n);
+    double *means = reinterpret_cast<double *>(gsum + (size_t)(chunk_max / BIGFFT_PGROUP + BIG_MAX_PIECES) * n);
+    BigChunk ch{};
+    auto flush = [&] {
+        if (ch.npieces == 0)
+            return;
+        if (b.detrend == 3)
+            hipLaunchKernelGGL(bigfft_mean_kernel, dim3(2 * ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, n, means);
+        if (n1 == 128)
+            hipLaunchKernelGGL((bigfft_col_kernel<128, 32>), dim3(BIG_N2 / 32, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
+                               means, T);
+        else if (n1 == 256)
+            hipLaunchKernelGGL((bigfft_col_kernel<256, 16>), dim3(BIG_N2 / 16, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
+                               means, T);
+        else
+            hipLaunchKernelGGL((bigfft_col_kernel<512, 16>), dim3(BIG_N2 / 16, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
+                               means, T);
+        hipLaunchKernelGGL(bigfft_row_kernel, dim3(n1 / 16, ch.ngroups), dim3(BIGFFT_THREADS), 0, s, ch, T, tw, gsum, n, n1);
+        hipLaunchKernelGGL(bigfft_fold_kernel, dim3(BIG_N2 / 16, n1 / 16, ch.npieces), dim3(BIGFFT_THREADS), 0, s, ch, gsum, n, n1);
+        ch.npieces = ch.npairs = ch.ngroups = 0;
+    };
     for (int ji = 0; ji < b.njobs; ++ji) {
         const SegJob &job = b.jobs[ji];
         if (job.fspan >= 0 || job.nblocks != 1)
             return hipErrorInvalidValue; // (frames are decoded into f32 streams at these sizes; one partial row per job)
         const int pairs = (job.nseg + 1) / 2;
-        for (int p0 = 0; p0 < pairs; p0 += chunk_max) {
-            const int np = std::min(chunk_max, pairs - p0);
-            hipLaunchKernelGGL(bigfft_load_kernel, dim3(np), dim3(BIGFFT_THREADS), 0, s, job, b.hop, b.detrend, n, win, buf[0], p0);
-            int cur = 0, ns = n, st = 1;
-            auto pass = [&](auto radix) {
-                constexpr int R = decltype(radix)::value;
-                const long long work = (long long)(n / R) * np;
-                hipLaunchKernelGGL(bigfft_pass_kernel<R>, dim3((unsigned)((work + BIGFFT_THREADS - 1) / BIGFFT_THREADS)), dim3(BIGFFT_THREADS), 0,
-                                   s, buf[cur], buf[cur ^ 1], tw, n, ns, st, np);
-                ns /= R;
-                st *= R;
-                cur ^= 1;
-            };
-            while (ns > 1) { // radix-16 passes, then whatever is left (32768 = 16^3 x 8, 65536 = 16^4, 131072 = 16^4 x 2)
-                if (ns % 16 == 0)
-                    pass(std::integral_constant<int, 16>{});
-                else if (ns % 8 == 0)
-                    pass(std::integral_constant<int, 8>{});
-                else if (ns % 4 == 0)
-                    pass(std::integral_constant<int, 4>{});
-                else
-                    pass(std::integral_constant<int, 2>{});
+        for (int done = 0; done < pairs;) {
+            // a job split over chunks is split at a multiple of the group size: its additions keep their order whatever else is in the batch
+            int take = std::min(pairs - done, chunk_max - ch.npairs);
+            if (take < pairs - done && chunk_max >= BIGFFT_PGROUP)
+                take = take / BIGFFT_PGROUP * BIGFFT_PGROUP;
+            if (take <= 0 || ch.npieces == BIG_MAX_PIECES) {
+                flush();
+                continue;
             }
-            const unsigned kb = (unsigned)((n + BIGFFT_THREADS - 1) / BIGFFT_THREADS);
-            const int groups = (np + BIGFFT_PGROUP - 1) / BIGFFT_PGROUP;
-            float *gsum = reinterpret_cast<float *>(buf[cur ^ 1]); // (groups * n floats <= np * n complex elements: it fits)
-            hipLaunchKernelGGL(bigfft_power_kernel, dim3(kb, (unsigned)groups), dim3(BIGFFT_THREADS), 0, s, buf[cur], gsum, n, np);
-            hipLaunchKernelGGL(bigfft_fold_kernel, dim3(kb), dim3(BIGFFT_THREADS), 0, s, gsum, job.partial, n, groups, p0 > 0 ? 1 : 0);
+            BigPiece &pc = ch.pieces[ch.npieces++];
+            pc.job = job;
+            pc.pair0 = done;
+            pc.npairs = take;
+            pc.tpair0 = ch.npairs;
+            pc.group0 = ch.ngroups;
+            pc.accumulate = done > 0;
+            ch.npairs += take;
+            ch.ngroups += (take + BIGFFT_PGROUP - 1) / BIGFFT_PGROUP;
+            done += take;
         }
     }
+    flush();
     return hipGetLastError();
 }
 

@@ -182,14 +182,15 @@ bool welch_supported(int n);
 // exp(i pi j^2 / n) (n entries), bhat = FFT_M of the chirp wrapped around M (M entries).
 int bluestein_size(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, const cf *chirp, const cf *bhat, hipStream_t s);
-// powers of two above what an LDS frame holds (bigfft.hip: 32768 ... BIGFFT_MAX_N): the same jobs through a Stockham FFT whose
-// passes go through `scratch` (>= 2 n complex elements: two frames of as many segment pairs as fit -- a chunk of pairs goes through
-// each pass together, BIGFFT_SCRATCH_ELEMS gives 512 pairs at n = 32768 and 128 at 131072), tw[j] = W_n^j; ONE partial row per
-// job (welch_segments_per_tile is "all of them" at these sizes)
+// powers of two above what an LDS frame holds (bigfft.hip: 32768 ... BIGFFT_MAX_N): the same jobs through a four-step transform
+// n = n/256 x 256 whose one intermediate frame lives in `scratch` -- every job of the batch shares the launches of a chunk of as many
+// segment pairs as fit (BIGFFT_SCRATCH_ELEMS: 960 pairs at n = 32768, 224 at 131072; chunk_limit > 0 caps it: a test hook) --,
+// tw[j] = W_n^j; ONE partial row per job (welch_segments_per_tile is "all of them" at these sizes)
 constexpr int BIGFFT_MAX_N = 131072;
 constexpr size_t BIGFFT_SCRATCH_ELEMS = (size_t)2 << 24; // 256 MiB of complex f32
 bool bigfft_size(int n);
-hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, hipStream_t s);
+hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, int chunk_limit,
+                            hipStream_t s);
 bool fused_supported(int n);                 // N = 256 ... 16384
 bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
 bool fused_double_supported(int n);          // overlap 0: sizes whose kernel transforms two disjoint segments at once

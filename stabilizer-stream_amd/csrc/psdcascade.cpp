@@ -119,6 +119,7 @@ struct psdc_handle {
     cf *d_chirp = nullptr, *d_bhat = nullptr; // chirp-z tables of a size that is not a power of two (launch_welch)
     cf *d_bigfft = nullptr;                   // n > 16384: the ping-pong frames of the global-memory FFT (launch_welch_big)
     size_t bigfft_elems = 0;
+    int bigfft_chunk_limit = 0;               // PSDC_DBG_BIGFFT_CHUNK at create: pairs per chunk (tests: a job split over chunks)
     int detrend = PSDC_DETREND_NONE;
     uint32_t avg_limit = 0xFFFFFFFFu, avg_count = 0xFFFFFFFFu;
     std::vector<Channel> ch;
@@ -1259,7 +1260,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         if (!prof_fused && (rc = prof_begin(pe, true)))
             return rc;
         if (bigfft_size((int)h->n))
-            HIPCHK(h, launch_welch_big((int)h->n, wb, h->d_win, h->d_tw, h->d_bigfft, h->bigfft_elems, h->stream));
+            HIPCHK(h, launch_welch_big((int)h->n, wb, h->d_win, h->d_tw, h->d_bigfft, h->bigfft_elems, h->bigfft_chunk_limit, h->stream));
         else
             HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->d_chirp, h->d_bhat, h->stream));
         if (!prof_fused && (rc = prof_end(pe, first, true)))
@@ -1726,6 +1727,8 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
                                          : (size_t)(fused_max_blocks((int)n) + WELCH_MAX_BLOCKS + 4 * MAX_JOBS) * n;
     if (bigfft_size((int)n)) {
         h->bigfft_elems = BIGFFT_SCRATCH_ELEMS;
+        if (const char *e = getenv("PSDC_DBG_BIGFFT_CHUNK"))
+            h->bigfft_chunk_limit = atoi(e);
         if ((e = hipMalloc(&h->d_bigfft, sizeof(cf) * h->bigfft_elems)) != hipSuccess)
             return dev_fail(e, "hipMalloc(big FFT frames)");
     }

@@ -184,7 +184,7 @@ hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *
 }
 
 // ---- bigfft.hip (n > 16384): the same jobs, ONE partial row each, scratch for at least one pair -----------------------
-hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, hipStream_t s)
+hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const cf *tw, cf *scratch, size_t scratch_elems, int chunk_limit, hipStream_t s)
 {
     if (!bigfft_size(n) || !scratch || scratch_elems < 2 * (size_t)n)
         return hipErrorInvalidValue;

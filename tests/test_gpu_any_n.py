@@ -81,7 +81,7 @@ def test_size_limits(pkg, gpu_required):
                                            (65536, "midpoint", (3, 40)), (131072, "none", None)])
 def test_fft_sizes_above_an_lds_frame(pkg, ora, gpu_required, n, detrend, avg):
     """Powers of two 32768 ... 131072 (`FftPlanner::plan_fft_forward(N)` takes any N, src/psd.rs:417-418; the reference's own stack
-    frames bound what it can run): the generic path with a Stockham FFT through global memory (csrc/bigfft.hip).  White noise,
+    frames bound what it can run): the generic path with a four-step FFT through global memory (csrc/bigfft.hip).  White noise,
     host-fed in odd chunks then device-fed, a read-out in between: counters exactly, every stage against the f64 oracle (pure 1e-5
     where a plain-sum stage has >= 4 averages and no detrend nulls a bin)."""
     import torch
@@ -102,3 +102,31 @@ def test_fft_sizes_above_an_lds_frame(pkg, ora, gpu_required, n, detrend, avg):
     g.close()
     with pytest.raises(pkg.PsdError):
         pkg.PsdCascadeBank(262144)  # beyond the largest size
+
+
+def test_big_fft_batches_and_chunk_splits(pkg, ora, gpu_required, monkeypatch):
+    """The four-step path shares its launches between every job of a round and splits a job that does not fit a chunk at a multiple
+    of its group size (csrc/bigfft.hip `launch_welch_big`): two channels of ~50 segment pairs each, Mean detrend (the per-segment
+    means ride in the chunk too), once with the chunk the scratch allows and once capped at 16 pairs (`PSDC_DBG_BIGFFT_CHUNK`: jobs
+    split four ways, chunks holding pieces of two jobs).  Both against the f64 oracle, and bit-identical to each other: the order of
+    the additions into a job's row does not depend on what else was in the batch."""
+    n = 32768
+    total = 101 * (n // 2) + 77
+    xs = [pkg.noise_host(total, seed=4100 + c) for c in range(2)]
+    outs = []
+    for limit in (None, "16"):
+        if limit:
+            monkeypatch.setenv("PSDC_DBG_BIGFFT_CHUNK", limit)
+        else:
+            monkeypatch.delenv("PSDC_DBG_BIGFFT_CHUNK", raising=False)
+        g = pkg.PsdCascadeBank(n, n_channels=2)
+        g.set_detrend(pkg.Detrend.MEAN)
+        for c in range(2):
+            g.process(c, xs[c])
+        for c in range(2):
+            check_against_oracle(pkg, ora, g, [xs[c]], n, detrend="mean", channel=c, what=f"N={n} channel {c} of two, chunk limit {limit}")
+        outs.append([g.stage_spectrum(c, s) for c in range(2) for s in range(g.num_stages(c))])
+        g.close()
+    assert len(outs[0]) == len(outs[1])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

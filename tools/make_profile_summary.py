@@ -29,7 +29,7 @@ def dominant(rows, counter=None):
     tot = {}
     for r in rows:
         k = r["Kernel_Name"]
-        if "fused_kernel" not in k and "fused3_kernel" not in k and "welch_kernel" not in k:
+        if "fused_kernel" not in k and "fused3_kernel" not in k and "welch_kernel" not in k and "bigfft_" not in k:
             continue
         if ksub and ksub not in k:
             continue
