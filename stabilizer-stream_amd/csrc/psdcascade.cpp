@@ -2080,8 +2080,8 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
     // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them, and a device that is still
     // busy with earlier rounds (when it is idle nothing is ever held back).
-    // (hipStreamQuery is the dearest thing on this path -- tens of microseconds, against a span's ~75-100 us of kernel time: it is
-    // asked at most ONCE per call; a "busy" answer stands for the rest of the call)
+    // (the stream is asked at most ONCE per call -- ~0.1 us on an idle or a busy stream, tools/probes/stream_query.cpp; a "busy" answer
+    // stands for the rest of the call)
     bool flush = c.submitted, known_busy = false;
     if (c.has_span()) {
         if (!in_place || c.fill > 0 || c.spans.size() >= h->coalesce)
