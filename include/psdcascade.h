@@ -131,7 +131,7 @@ typedef struct psdc_profile {
  * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about a third of the rate;
  * sizes that are not powers of two evaluate the DFT in chirp-z form on a power-of-two transform of at
  * least twice the length: two such transforms per segment pair); the powers of two 32768 ... 131072 a four-step FFT with
- * one intermediate frame in device memory (85 ... 120 GS/s, +256 MiB per handle). */
+ * one intermediate frame in device memory (100 ... 120 GS/s, +256 MiB per handle). */
 psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int device);
 
 /* The same with a caller-supplied `Window<N>` -- the struct is public with public fields `win`, `power`,

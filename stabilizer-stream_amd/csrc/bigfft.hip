@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fft_core.h"
 #include "kernels.h"
@@ -79,16 +80,16 @@ struct ColFrame {
 
 // One in-LDS Stockham pass of radix R over the N1 index of every column of the tile (ns, s as in bigfft_pass_kernel); the LAST pass
 // hands its outputs (k1 natural) to `out(k1, c, value)` instead of storing them back.
-template <int N1, int C, int R, int NS, int S, bool LAST, typename Out>
+template <int N1, int C, int TH, int R, int NS, int S, bool LAST, typename Out>
 __device__ __forceinline__ void col_lds_pass(cf *frame, const cf *__restrict__ tw, int n, int tid, Out out)
 {
     using F = ColFrame<N1, C>;
-    constexpr int NB = (N1 / R) * C, PER = NB / BIGFFT_THREADS, M = NS / R;
-    static_assert(NB % BIGFFT_THREADS == 0, "butterflies per thread");
+    constexpr int NB = (N1 / R) * C, PER = NB / TH, M = NS / R;
+    static_assert(NB % TH == 0, "butterflies per thread");
     cf v[PER][R];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int b = tid + i * BIGFFT_THREADS, c = b % C, t = b / C;
+        const int b = tid + i * TH, c = b % C, t = b / C;
         const int p = t / S, q = t % S;
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -98,7 +99,7 @@ __device__ __forceinline__ void col_lds_pass(cf *frame, const cf *__restrict__ t
         __syncthreads(); // (in place: every read before any store)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int b = tid + i * BIGFFT_THREADS, c = b % C, t = b / C;
+        const int b = tid + i * TH, c = b % C, t = b / C;
         const int p = t / S, q = t % S;
         Dft<R>::run(v[i]);
 #pragma unroll
@@ -117,14 +118,14 @@ __device__ __forceinline__ void col_lds_pass(cf *frame, const cf *__restrict__ t
         __syncthreads();
 }
 
-template <int N1, int C>
-__global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_col_kernel(const BigChunk ch, int hop, int detrend, const float *__restrict__ win,
+template <int N1, int C, int TH>
+__global__ __launch_bounds__(TH) void bigfft_col_kernel(const BigChunk ch, int hop, int detrend, const float *__restrict__ win,
                                                                     const cf *__restrict__ tw, const double *__restrict__ means,
                                                                     cf *__restrict__ T)
 {
     using F = ColFrame<N1, C>;
-    constexpr int n = N1 * BIG_N2, M = N1 / 16, NB = M * C, PER = NB / BIGFFT_THREADS;
-    static_assert(NB % BIGFFT_THREADS == 0, "butterflies per thread");
+    constexpr int n = N1 * BIG_N2, M = N1 / 16, NB = M * C, PER = NB / TH;
+    static_assert(NB % TH == 0, "butterflies per thread");
     __shared__ cf frame[F::ELEMS];
     // The workgroups of one pair (and of its neighbours, which share half their samples) on ONE XCD, whose L2 then holds the lines
     // they share: the dispatcher deals consecutive workgroup ids round the eight XCDs.
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_col_kernel(const BigChu
     // pass 1 (radix 16, sub-transform length N1, stride 1): butterfly p of column c takes rows p + M r
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int b = tid + i * BIGFFT_THREADS, c = b % C, p = b / C;
+        const int b = tid + i * TH, c = b % C, p = b / C;
         cf v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -194,13 +195,13 @@ __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_col_kernel(const BigChu
     cf *Tp = T + (size_t)pq * n + (size_t)(c0 >> 4) * (N1 * 16);
     auto store = [&](int k1, int c, cf y) { Tp[(c >> 4) * (N1 * 16) + k1 * 16 + (c & 15)] = y; };
     if constexpr (N1 == 128)
-        col_lds_pass<N1, C, 8, 8, 16, true>(frame, tw, n, tid, store);
+        col_lds_pass<N1, C, TH, 8, 8, 16, true>(frame, tw, n, tid, store);
     else if constexpr (N1 == 256)
-        col_lds_pass<N1, C, 16, 16, 16, true>(frame, tw, n, tid, store);
+        col_lds_pass<N1, C, TH, 16, 16, 16, true>(frame, tw, n, tid, store);
     else {
         static_assert(N1 == 512, "N1");
-        col_lds_pass<N1, C, 16, 32, 16, false>(frame, tw, n, tid, store);
-        col_lds_pass<N1, C, 2, 2, 256, true>(frame, tw, n, tid, store);
+        col_lds_pass<N1, C, TH, 16, 32, 16, false>(frame, tw, n, tid, store);
+        col_lds_pass<N1, C, TH, 2, 2, 256, true>(frame, tw, n, tid, store);
     }
 }
 
@@ -218,9 +219,19 @@ __global__ __launch_bounds__(BIGFFT_THREADS) void bigfft_mean_kernel(const BigCh
         return;
     }
     const float *x = job.src + ((job.seg0 + l) * (long long)hop - job.src_base);
-    double s = 0.0;
-    for (int j = tid; j < n; j += BIGFFT_THREADS)
-        s += (double)x[j];
+    // sixteen independent loads a lane in flight (n is a multiple of 4096 here): the dependent chain of a plain loop is what this
+    // kernel's time was (Mean at N = 131072 read 58 GS/s against 104 without detrend)
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j0 = 0; j0 < n; j0 += 16 * BIGFFT_THREADS) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            v[u] = x[j0 + u * BIGFFT_THREADS + tid];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            s4[u & 3] += (double)v[u];
+    }
+    double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     for (int o = 32; o > 0; o >>= 1)
         s += __shfl_xor(s, o);
     if ((tid & 63) == 0)
@@ -338,15 +349,19 @@ hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const 
             return;
         if (b.detrend == 3)
             hipLaunchKernelGGL(bigfft_mean_kernel, dim3(2 * ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, n, means);
+        auto col = [&](auto n1c, auto cc, auto thc) {
+            constexpr int N1 = decltype(n1c)::value, C = decltype(cc)::value, TH = decltype(thc)::value;
+            hipLaunchKernelGGL((bigfft_col_kernel<N1, C, TH>), dim3(BIG_N2 / C, ch.npairs), dim3(TH), 0, s, ch, b.hop, b.detrend, win, tw, means, T);
+        };
+        using std::integral_constant;
+        // columns a workgroup x threads: ONE first-pass butterfly a thread (two at N1 = 512 measured -21 %); 32 columns with 512 threads
+        // at N1 = 256 (128-byte instead of 64-byte row pieces) measured the same as 16 with 256
         if (n1 == 128)
-            hipLaunchKernelGGL((bigfft_col_kernel<128, 32>), dim3(BIG_N2 / 32, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
-                               means, T);
+            col(integral_constant<int, 128>{}, integral_constant<int, 32>{}, integral_constant<int, 256>{});
         else if (n1 == 256)
-            hipLaunchKernelGGL((bigfft_col_kernel<256, 16>), dim3(BIG_N2 / 16, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
-                               means, T);
+            col(integral_constant<int, 256>{}, integral_constant<int, 16>{}, integral_constant<int, 256>{});
         else
-            hipLaunchKernelGGL((bigfft_col_kernel<512, 16>), dim3(BIG_N2 / 16, ch.npairs), dim3(BIGFFT_THREADS), 0, s, ch, b.hop, b.detrend, win, tw,
-                               means, T);
+            col(integral_constant<int, 512>{}, integral_constant<int, 16>{}, integral_constant<int, 512>{});
         hipLaunchKernelGGL(bigfft_row_kernel, dim3(n1 / 16, ch.ngroups), dim3(BIGFFT_THREADS), 0, s, ch, T, tw, gsum, n, n1);
         hipLaunchKernelGGL(bigfft_fold_kernel, dim3(BIG_N2 / 16, n1 / 16, ch.npieces), dim3(BIGFFT_THREADS), 0, s, ch, gsum, n, n1);
         ch.npieces = ch.npairs = ch.ngroups = 0;
