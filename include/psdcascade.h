@@ -75,7 +75,8 @@ extern "C" {
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
 #define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that may share one round while the device is
-                             * still busy with earlier ones (1..16, default 8; 1 = every span its own round;
+                             * still busy with earlier ones (1..16; default: 8, and 16 for a single channel fed in spans of
+                             * at most 2^25 samples -- a round costs ~20 us whatever it holds; 1 = every span its own round;
                              * -k: hold k spans back even on an idle device -- for tests) */
 #define PSDC_OPT_PROFILE 2 /* 1: time the dominant kernel with HIP events (psdc_profile_read) */
 #define PSDC_OPT_MIN_PAIRS 4 /* segment pairs a decimated stage (k >= 1) collects before it issues work on the ingest

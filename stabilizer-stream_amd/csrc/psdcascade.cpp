@@ -152,6 +152,7 @@ struct psdc_handle {
     int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
     uint32_t coalesce = 8; // zero-copy spans per channel held back while the device is busy (1 = none)
+    bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or MAX_COALESCE for one channel fed in short spans (coalesce_limit)
     uint32_t stage_limit = MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
     bool coalesce_always = false; // hold them back even when the device is idle (tests)
@@ -675,6 +676,17 @@ int collect_profile(psdc_handle *h)
 }
 
 // nothing of this handle is executing or queued on the device
+// In-place spans of a channel that may share a round.  A round costs ~20 us of launch boundaries whatever it holds (the post
+// launch and two dependent dispatches): 8 spans of 2^26 samples are 0.7 ms of kernel, 8 of 2^22 are 50 us -- so a single channel fed in
+// spans of at most 2^25 samples may hold sixteen (2^24 a call: +3 %, 2^22: +21 %; eight channels x 2^24 measured -2 % with sixteen and stay
+// at eight).  An explicit PSDC_OPT_COALESCE is taken as given.
+uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len = 0)
+{
+    if (h->coalesce_auto && h->n_channels == 1 && std::max(c.span_max, len) <= ((size_t)1 << 25))
+        return MAX_COALESCE;
+    return h->coalesce;
+}
+
 bool device_idle(psdc_handle *h) { return !h->coalesce_always && hipStreamQuery(h->stream) == hipSuccess; }
 
 // One round of the cascade pipeline: every (channel, stage) that has complete
@@ -908,7 +920,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             const size_t need = (size_t)(t_next - kf_after(w.c, w.k + 1));
             size_t grow_to = 0;
             if (c.span_max) {
-                const uint64_t round_max = (uint64_t)c.span_max * (c.coalesced_seen ? h->coalesce : 1);
+                const uint64_t round_max = (uint64_t)c.span_max * (c.coalesced_seen ? coalesce_limit(h, c) : 1);
                 const unsigned sh = 3u * (w.k + 1);
                 grow_to = (size_t)(sh < 64 ? round_max >> sh : 0) + (size_t)4 * (h->n + HBF_HALO) + 64;
             }
@@ -1963,6 +1975,7 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
         if (rc)
             return rc;
         h->coalesce = (uint32_t)k;
+        h->coalesce_auto = false;
         h->coalesce_always = value < 0;
         return PSDC_OK;
     }
@@ -2084,7 +2097,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     // stands for the rest of the call)
     bool flush = c.submitted, known_busy = false;
     if (c.has_span()) {
-        if (!in_place || c.fill > 0 || c.spans.size() >= h->coalesce)
+        if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len))
             flush = true;
         else if (device_idle(h))
             flush = true;
@@ -2124,7 +2137,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
             c.coalesced_seen = true;
     }
     if (h->n_channels == 1) {
-        if (c.has_span() && !c.submitted && c.spans.size() < h->coalesce && (known_busy || !device_idle(h)))
+        if (c.has_span() && !c.submitted && c.spans.size() < coalesce_limit(h, c) && (known_busy || !device_idle(h)))
             return PSDC_OK; // the device is busy: the next span may share this one's round
         return advance(h);
     }
@@ -2731,6 +2744,7 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->quantum = h->quantum;
     o->profile = h->profile;
     o->coalesce = h->coalesce;
+    o->coalesce_auto = h->coalesce_auto;
     o->coalesce_always = h->coalesce_always;
     o->stage_limit = h->stage_limit;
     o->min_pairs = h->min_pairs;
