@@ -217,6 +217,19 @@ int psdc_record_consumed(psdc_handle *h, void *consumed_event);
 int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
                                size_t n_frames, size_t *n_ok);
 
+/* Frame::from_bytes + Payload::traces for ANY of the reference's four payload formats (src/de/mod.rs:12-17,
+ * src/de/frame.rs:49-60, src/de/data.rs): AdcDac (id 1: traces ADC0, ADC1, DAC0, DAC1, eight samples per batch), Fls (2: AR, AP,
+ * BI, BQ), ThermostatEem (3: T00, T20, I0, I1), Mpll (4: "phase (rad)", "frequency (kHz)", "amplitude (V/G10)") -- one sample
+ * per batch for the last three --, + Loss::update + process() of trace i into channel i (src/bin/psd.rs:174-182: the trace's
+ * index picks the cascade, whatever the frame's format), for `n_frames` frames of `frame_size` bytes each in host memory.
+ * The format is each frame's own (header byte 2); the frames of a call are taken in runs of one format, headers validated on
+ * the host, payloads decoded on the device -- the decoded traces are bit-identical to Payload::traces (same f32 operations in
+ * the same order).  On a bad frame: frames before it are ingested, *n_ok says how many, and the frame's de::Error is returned
+ * (PSDC_ERR_FRAME_HEADER / _FORMAT / _SIZE).  Needs n_channels >= the traces of every format met (4, 4, 4, 3), else
+ * PSDC_ERR_ARG at the first frame that carries more.  (The reference CLI's default --frame-size 1448 is 60 Mpll batches,
+ * src/source.rs:31.)  psdc_process_adcdac_frames is this call restricted to AdcDac. */
+int psdc_process_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size, size_t n_frames, size_t *n_ok);
+
 /* The same for frames that already sit in device memory (a capture buffer filled by a NIC / another kernel).
  * Headers: Header::parse and the AdcDac size checks of every frame plus the Loss sums are ONE small launch on a side stream
  *   of the handle; the call waits for that launch alone, so `*n_ok` and the returned de::Error are final when it returns.
@@ -235,7 +248,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                                       size_t n_frames, size_t *n_ok);
 
 /* Loss (src/loss.rs:3-26): sequence-gap accounting over the frames ingested by
- * psdc_process_adcdac_frames.  received counts batches; dropped the batches missing
+ * psdc_process_frames / psdc_process_adcdac_frames[_device].  received counts batches; dropped the batches missing
  * between consecutive frames (u32 wrapping_sub); gaps are counted, never zero-filled. */
 typedef struct psdc_loss {
     uint64_t received;

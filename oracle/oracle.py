@@ -89,6 +89,8 @@ def _declare(L):
     L.ora_var_eval.argtypes = [i32, i32, C.c_float, sz, fp, fp, sz, C.c_float]
     L.ora_trace_plot.restype = C.c_long
     L.ora_trace_plot.argtypes = [fp, fp, sz, C.c_float, i32, C.c_float, C.c_float, fp, dp]
+    L.ora_frame_decode.restype = i32
+    L.ora_frame_decode.argtypes = [C.POINTER(C.c_uint8), sz, fp, fp, fp, fp] + [C.POINTER(C.c_uint32)] * 5
     L.ora_adcdac_decode.restype = i32
     L.ora_adcdac_decode.argtypes = [C.POINTER(C.c_uint8), sz, fp, fp, fp, fp,
                                     C.POINTER(u32), C.POINTER(u32)]
@@ -311,3 +313,23 @@ def adcdac_decode(frame):
                                  *[_ptr(t, C.c_float) for t in tr], seq, bat)
     n = 8 * bat.value if st == 0 else 0
     return st, seq.value, bat.value, [t[:n].copy() for t in tr]
+
+
+# trace labels of Payload::traces (src/de/data.rs:38-80, 98-138, 155, 181-207), by Format id (src/de/mod.rs:12-17)
+TRACE_NAMES = {1: ("ADC0", "ADC1", "DAC0", "DAC1"), 2: ("AR", "AP", "BI", "BQ"), 3: ("T00", "T20", "I0", "I1"),
+               4: ("phase (rad)", "frequency (kHz)", "amplitude (V/G10)")}
+
+
+def frame_decode(frame):
+    """Frame::from_bytes + Payload::traces for any of the four formats.
+    frame: bytes -> (status, format id, seq, batches, [(name, f32 array), ...])"""
+    b = np.frombuffer(bytes(frame), dtype=np.uint8)
+    cap = max(0, b.size - 8) // 8 + 8
+    tr = [np.zeros(cap, dtype=np.float32) for _ in range(4)]
+    fmt, ntr, ns, seq, bat = (C.c_uint32() for _ in range(5))
+    st = lib().ora_frame_decode(_ptr(b, C.c_uint8) if b.size else None, b.size, *[_ptr(t, C.c_float) for t in tr],
+                                fmt, ntr, ns, seq, bat)
+    out = []
+    if st == 0:
+        out = [(TRACE_NAMES[fmt.value][i], tr[i][:ns.value].copy()) for i in range(ntr.value)]
+    return st, fmt.value, seq.value, bat.value, out

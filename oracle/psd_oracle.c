@@ -3,8 +3,8 @@
  *
  * CPU restatement of the cascaded PSD hot path of quartiq/stabilizer-stream
  * (src/psd.rs: Window, Detrend, Psd, PsdStage, Break, MergeOpts, AvgOpts,
- * PsdCascade) plus src/var.rs Var::eval and the AdcDac payload decode
- * (src/de/frame.rs, src/de/data.rs:11-82).
+ * PsdCascade) plus src/var.rs Var::eval and the payload decoders
+ * (src/de/frame.rs, src/de/data.rs:11-212: AdcDac, Fls, ThermostatEem, Mpll).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this.  The shipped library (stabilizer-stream_amd/csrc) never does.
@@ -22,6 +22,11 @@
  *     response length are restated from the published crate (hbf_taps_oracle.h);
  *     PARITY UNPINNED for exact decimator output samples, pinned only by the
  *     reference's statistical assertions.
+ *   - payload decoders: AdcDac constants are the reference's (data.rs:28-35).  The
+ *     reference holds NO test or fixture for Fls / ThermostatEem / Mpll: PARITY
+ *     UNPINNED by reference-held vectors for those three -- pinned by hand-computed
+ *     known answers and a second independent (numpy) restatement that must agree
+ *     bit for bit (tests/test_payload_formats_oracle.py).
  *   - The Rust reference cannot be built here (no rustc/cargo; dependencies
  *     not vendored): there is no oracle/_ref.
  *
@@ -202,6 +207,80 @@ int ora_adcdac_decode(const uint8_t *frame, size_t len, float *adc0, float *adc1
                     v = (int16_t)((uint16_t)v + 0x8000u);
                 tr[ch][(size_t)b * 8 + (size_t)i] = (float)v * lsb;
             }
+        }
+    }
+    return 0;
+}
+
+/* ---- the other payload formats (src/de/mod.rs:9-17; src/de/frame.rs:49-60; src/de/data.rs:84-212): Fls (id 2), ThermostatEem
+ * (3), Mpll (4) -- ONE sample per batch and trace.  Any of the four formats:
+ * returns 0 ok; -1 InvalidHeader; -2 UnknownFormat; -3 PayloadSize; -4 would panic in the reference (len < 8, or
+ * payload / batch size != batches).  *fmt: the header's id; *ntraces 4, 4, 4, 3; tr[t] receives *nsamples f32 each
+ * (8 * batches for AdcDac, batches otherwise; every tr[t] must hold (len - 8) / 8 + 8 floats). */
+static int32_t ora_le_i32(const uint8_t *q)
+{
+    return (int32_t)((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24));
+}
+static float ora_le_f32(const uint8_t *q)
+{
+    const uint32_t u = (uint32_t)ora_le_i32(q);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+int ora_frame_decode(const uint8_t *frame, size_t len, float *tr0, float *tr1, float *tr2, float *tr3, uint32_t *fmt,
+                     uint32_t *ntraces, uint32_t *nsamples, uint32_t *seq, uint32_t *batches)
+{
+    *fmt = *ntraces = *nsamples = *seq = *batches = 0;
+    if (len < 8)
+        return -4; /* input[..HEADER_SIZE] panics (frame.rs:50) */
+    if (frame[0] != 0x7b || frame[1] != 0x05)
+        return -1; /* frame.rs:27-29 */
+    const uint8_t id = frame[2];
+    if (id < 1 || id > 4)
+        return -2; /* frame.rs:30, mod.rs:12-17 */
+    *fmt = id;
+    const uint32_t nb = frame[3];
+    *seq = (uint32_t)ora_le_i32(frame + 4);
+    *batches = nb;
+    if (id == 1) {
+        *ntraces = 4;
+        const int st = ora_adcdac_decode(frame, len, tr0, tr1, tr2, tr3, seq, batches);
+        if (st == 0)
+            *nsamples = 8 * nb;
+        return st;
+    }
+    /* bytes per batch: [[[u8;4];7];2] (data.rs:86), [[u8;4];16+4] (:144), [[u8;4];6] (:168) */
+    const size_t bb = id == 2 ? 56 : id == 3 ? 80 : 24;
+    const size_t plen = len - 8;
+    if (plen % bb != 0)
+        return -3; /* bytemuck::try_cast_slice (data.rs:91,149,173) */
+    if (plen / bb != nb)
+        return -4; /* assert_eq!(batches, data.len()) (data.rs:93,150,174) */
+    *ntraces = id == 4 ? 3 : 4;
+    *nsamples = nb;
+    const uint8_t *p = frame + 8;
+    for (uint32_t b = 0; b < nb; ++b, p += bb) {
+        if (id == 2) { /* Fls::traces, data.rs:97-139 */
+            const float re = (float)ora_le_i32(p), im = (float)ora_le_i32(p + 4);
+            /* (re as f32).powi(2) + (im as f32).powi(2), .sqrt(), * (1.0 / (i32::MAX as f32)) :104-107 */
+            tr0[b] = sqrtf(re * re + im * im) * (1.0f / (float)INT32_MAX);
+            /* b[0][2..4] as one i64 (:114-119), * (TAU / (1i64 << 16) as f32) */
+            const int64_t ph = (int64_t)((uint64_t)(uint32_t)ora_le_i32(p + 8) | ((uint64_t)(uint32_t)ora_le_i32(p + 12) << 32));
+            tr1[b] = (float)ph * (6.28318530717958647692f / (float)(1ll << 16));
+            tr2[b] = (float)ora_le_i32(p + 28) / (float)INT32_MAX; /* b[1][0] :127 */
+            tr3[b] = (float)ora_le_i32(p + 32) / (float)INT32_MAX; /* b[1][1] :134 */
+        } else if (id == 3) { /* ThermostatEem::traces, data.rs:154-163: words 0, 8, 13, 16 as f32 */
+            tr0[b] = ora_le_f32(p);
+            tr1[b] = ora_le_f32(p + 4 * 8);
+            tr2[b] = ora_le_f32(p + 4 * 13);
+            tr3[b] = ora_le_f32(p + 4 * 16);
+        } else { /* Mpll::traces, data.rs:178-211 */
+            const float two32 = (float)(1ull << 32);
+            tr0[b] = (float)ora_le_i32(p + 16) * (6.28318530717958647692f / two32);      /* phase (rad) :184 */
+            tr1[b] = (float)ora_le_i32(p + 20) * (1.0f / 1.28e-3f / two32);              /* frequency (kHz) :193 */
+            const float x0 = (float)ora_le_i32(p), x1 = (float)ora_le_i32(p + 4);
+            tr2[b] = sqrtf(x0 * x0 + x1 * x1) * (10.24f / 10.0f * 2.0f * 2.0f / two32); /* amplitude (V/G10) :202-206 */
         }
     }
     return 0;

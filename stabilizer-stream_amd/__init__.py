@@ -57,6 +57,24 @@ class Detrend(enum.IntEnum):
     LINEAR = 4
 
 
+class Format(enum.IntEnum):
+    """Stream payload formats (src/de/mod.rs:9-17)"""
+    ADC_DAC = 1
+    FLS = 2
+    THERMOSTAT_EEM = 3
+    MPLL = 4
+
+
+# labels of Payload::traces by format (src/de/data.rs:38-80, 98-138, 155, 181-207); trace i feeds channel i (src/bin/psd.rs:174-182)
+TRACE_NAMES = {
+    Format.ADC_DAC: ("ADC0", "ADC1", "DAC0", "DAC1"),
+    Format.FLS: ("AR", "AP", "BI", "BQ"),
+    Format.THERMOSTAT_EEM: ("T00", "T20", "I0", "I1"),
+    Format.MPLL: ("phase (rad)", "frequency (kHz)", "amplitude (V/G10)"),
+}
+BATCH_BYTES = {Format.ADC_DAC: 64, Format.FLS: 56, Format.THERMOSTAT_EEM: 80, Format.MPLL: 24}  # src/de/data.rs:13, 86, 144, 168
+
+
 class Window(enum.IntEnum):
     """Window::rectangular / Window::hann (src/psd.rs:24-55) by kind"""
     RECTANGULAR = 0
@@ -251,6 +269,7 @@ def lib():
     f("psdc_process_device_after", i32, [H, u32, C.c_void_p, sz, C.c_void_p])
     f("psdc_record_consumed", i32, [H, C.c_void_p])
     f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
+    f("psdc_process_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_process_adcdac_frames_device", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_loss_read", i32, [H, C.POINTER(_CLoss), i32])
     f("psdc_flush", i32, [H])
@@ -294,7 +313,7 @@ def lib():
 EXPORTS = [
     "psdc_abi_version", "psdc_last_error", "psdc_create", "psdc_destroy", "psdc_clone", "psdc_reset",
     "psdc_configure", "psdc_set_detrend", "psdc_set_avg", "psdc_process", "psdc_process_device",
-    "psdc_process_adcdac_frames", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
+    "psdc_process_adcdac_frames", "psdc_process_frames", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
     "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_read_channel", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
@@ -419,6 +438,16 @@ class PsdCascadeBank:
         ok = C.c_size_t(0)
         rc = self._L.psdc_process_adcdac_frames(self._h, buf.ctypes.data_as(C.c_void_p), frame_size,
                                                 n_frames, C.byref(ok))
+        if rc < 0:
+            _raise(rc, self._h)
+        return ok.value
+
+    def process_frames(self, data, frame_size):
+        """Frames of any of the four payload formats (src/de/mod.rs:12-17), each frame's own header naming its format: trace i of
+        every frame goes to channel i.  data: bytes-like holding whole frames; returns the number of frames ingested."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        ok = C.c_size_t(0)
+        rc = self._L.psdc_process_frames(self._h, buf.ctypes.data_as(C.c_void_p), frame_size, buf.size // frame_size, C.byref(ok))
         if rc < 0:
             _raise(rc, self._h)
         return ok.value

@@ -215,6 +215,11 @@ hipError_t launch_copy_out(float *h_dst, const float *d_src, size_t count, hipSt
 hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches,
                          float *dst0, float *dst1, float *dst2, float *dst3, hipStream_t s);
 
+// the other payload formats (src/de/data.rs:84-212; fmt 2 Fls, 3 ThermostatEem, 4 Mpll: 56 / 80 / 24 bytes a batch, one sample per
+// batch and trace, four / four / three traces -- dst3 unused for Mpll): dst[c] receives batches * n_frames samples of trace c
+hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, float *dst0, float *dst1,
+                          float *dst2, float *dst3, hipStream_t s);
+
 // device-resident frames: header checks of every frame (check != 0) and the Loss counters over the first n_loss, in ONE
 // launch; the four result words land in host_out (pinned host memory) when the stream has run the kernel: host_out[0] =
 // max ~(index << 2 | code) over the bad frames (0: none), [1] batches received, [2] sequence gaps, [3] first seq | next seq

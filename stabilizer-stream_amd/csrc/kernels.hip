@@ -660,6 +660,67 @@ __global__ __launch_bounds__(256) void adcdac_kernel(const uint8_t *__restrict__
     }
 }
 
+// The other payload formats (src/de/data.rs:84-212) -- Fls (format id 2), ThermostatEem (3), Mpll (4): ONE sample per batch and
+// trace.  One thread per (frame, batch).  The arithmetic is the reference's, operation by operation in f32 (`as f32` conversions,
+// separate products and sum -- rustc never fuses them --, a correctly rounded square root, the scale constants evaluated in f32
+// in the reference's order): the traces are bit-identical to Payload::traces.
+struct PayloadFmt {
+    int batch_bytes, ntraces;
+};
+__host__ __device__ constexpr PayloadFmt payload_fmt(int id)
+{
+    return id == 2 ? PayloadFmt{56, 4}   // [[[u8;4];7];2]  data.rs:86
+         : id == 3 ? PayloadFmt{80, 4}   // [[u8;4];16+4]   data.rs:144
+                   : PayloadFmt{24, 3};  // [[u8;4];6]      data.rs:168
+}
+template <int FMT>
+__global__ __launch_bounds__(256) void payload_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames, int batches,
+                                                      float *d0, float *d1, float *d2, float *d3)
+{
+    constexpr int BB = payload_fmt(FMT).batch_bytes;
+    const size_t total = n_frames * (size_t)batches;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t f = g / (size_t)batches, b = g % (size_t)batches;
+        const uint8_t *p = frames + f * frame_size + 8 + b * BB;
+        auto word = [&](int i) { // u32::from_le_bytes of word i of the batch (any base alignment)
+            const uint8_t *q = p + 4 * i;
+            return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        };
+        auto i32f = [&](int i) { return (float)(int32_t)word(i); }; // i32::from_le_bytes(..) as f32
+        // a.powi(2) + c.powi(2), .sqrt(): two products, one sum, a correctly rounded root.  (HIP's __fmul_rn / __fadd_rn are plain
+        // operators the backend may fuse, and __fsqrt_rn is the approximate native root: the pragma and sqrtf -- IEEE under hipcc's
+        // default -fhip-fp32-correctly-rounded-divide-sqrt -- are what pins the arithmetic.)
+        auto hyp = [](float a, float c) {
+#pragma clang fp contract(off)
+            const float aa = a * a, cc = c * c;
+            const float sum = aa + cc;
+            return sqrtf(sum);
+        };
+        if constexpr (FMT == 2) { // Fls::traces, data.rs:97-139
+            constexpr float inv_max = 1.0f / 2147483648.0f;                // 1.0 / (i32::MAX as f32)
+            constexpr float ap = 6.28318530717958647692f / 65536.0f;       // TAU / (1i64 << 16) as f32
+            d0[g] = hyp(i32f(0), i32f(1)) * inv_max;                       // "AR" :100-110
+            const long long ph = (long long)((unsigned long long)word(2) | ((unsigned long long)word(3) << 32));
+            d1[g] = (float)ph * ap;                                        // "AP" :111-123
+            d2[g] = i32f(7) / 2147483648.0f;                               // "BI" b[1][0] :124-130 (a power of two: exact)
+            d3[g] = i32f(8) / 2147483648.0f;                               // "BQ" b[1][1] :131-137
+        } else if constexpr (FMT == 3) { // ThermostatEem::traces, data.rs:154-163: words 0, 8, 13, 16 as f32
+            d0[g] = __uint_as_float(word(0));
+            d1[g] = __uint_as_float(word(8));
+            d2[g] = __uint_as_float(word(13));
+            d3[g] = __uint_as_float(word(16));
+        } else { // Mpll::traces, data.rs:178-211
+            constexpr float two32 = 4294967296.0f;
+            constexpr float c_phase = 6.28318530717958647692f / two32;     // TAU / (1u64 << 32) as f32
+            constexpr float c_freq = 1.0f / 1.28e-3f / two32;              // 1.0 / 1.28e-3 / (1u64 << 32) as f32
+            constexpr float c_amp = 10.24f / 10.0f * 2.0f * 2.0f / two32;  // 10.24 / 10.0 * 2.0 * 2.0 / (1u64 << 32) as f32
+            d0[g] = i32f(4) * c_phase;                                     // "phase (rad)"
+            d1[g] = i32f(5) * c_freq;                                      // "frequency (kHz)"
+            d2[g] = hyp(i32f(0), i32f(1)) * c_amp;                         // "amplitude (V/G10)"
+        }
+    }
+}
+
 // Device-resident frames, one pass: Header::parse (src/de/frame.rs:25-37) + the AdcDac size checks (src/de/data.rs:22-25) of
 // every frame, in the reference's order -- acc[0] <- max over the bad frames of ~(index << 2 | code) (code 1 InvalidHeader,
 // 2 UnknownFormat, 3 PayloadSize / batches mismatch), i.e. the FIRST bad frame; 0 if all are good -- and Loss::update
@@ -943,6 +1004,24 @@ hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_fram
         blocks = 4096;
     hipLaunchKernelGGL(adcdac_kernel, dim3((unsigned)blocks), dim3(256), 0, s, frames, frame_size,
                        n_frames, batches, dst0, dst1, dst2, dst3);
+    return hipGetLastError();
+}
+
+hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, float *dst0, float *dst1,
+                          float *dst2, float *dst3, hipStream_t s)
+{
+    const size_t total = n_frames * (size_t)batches;
+    if (total == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(4096, (total + 255) / 256);
+    if (fmt == 2)
+        hipLaunchKernelGGL(payload_kernel<2>, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, dst0, dst1, dst2, dst3);
+    else if (fmt == 3)
+        hipLaunchKernelGGL(payload_kernel<3>, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, dst0, dst1, dst2, dst3);
+    else if (fmt == 4)
+        hipLaunchKernelGGL(payload_kernel<4>, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, batches, dst0, dst1, dst2, dst3);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -2144,8 +2144,27 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     return PSDC_OK;
 }
 
-int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size,
-                               size_t n_frames, size_t *n_ok)
+namespace {
+// Payload layouts by Format id (src/de/mod.rs:12-17; src/de/data.rs:13, 86, 144, 168): bytes per batch, samples per batch and
+// trace, traces (Payload::traces).
+struct WireFmt {
+    int id;
+    size_t batch_bytes;
+    int spb, ntr;
+    const char *what;
+};
+const WireFmt *wire_fmt(int id)
+{
+    static const WireFmt t[4] = {{1, 64, 8, 4, "AdcDac"}, {2, 56, 1, 4, "Fls"}, {3, 80, 1, 4, "ThermostatEem"}, {4, 24, 1, 3, "Mpll"}};
+    return id >= 1 && id <= 4 ? &t[id - 1] : nullptr;
+}
+
+// Frames in host memory, frame by frame as Source::get does for Data::File / Data::Udp (src/source.rs:135-142, 158-165):
+// Frame::from_bytes (src/de/frame.rs:49-60), Loss::update (src/loss.rs:11-26), Payload::traces into channels 0 .. ntraces - 1
+// (src/bin/psd.rs:174-182: trace i goes to cascade i whatever the frame's format).  The frames are taken in RUNS of one format:
+// within a run the headers are validated on the host, the payloads uploaded in pieces and decoded on the device.
+// adcdac_only: any other valid format id is de::Error::UnknownFormat's code, as psdc_process_adcdac_frames documents.
+int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, size_t frame_size, size_t n_frames, size_t *n_ok)
 {
     if (n_ok)
         *n_ok = 0;
@@ -2153,7 +2172,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
     if (rc)
         return rc;
     ON_DEVICE(h, h->device);
-    if (h->n_channels < 4)
+    if (adcdac_only && h->n_channels < 4)
         return fail(h, PSDC_ERR_ARG, "AdcDac frames carry four traces: need n_channels >= 4");
     if (n_frames == 0)
         return PSDC_OK;
@@ -2161,43 +2180,70 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
         return fail(h, PSDC_ERR_ARG, "null input");
     if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
         return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
-    // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25) and keep the loss
-    // counters (Loss::update, src/loss.rs:11-26), piece by piece inside the upload loop below so
-    // that the scan of one piece runs while the piece before it is on the link
     size_t good = 0;
     int bad = PSDC_OK;
     const size_t payload = frame_size - 8;
-    const int batches = (int)(payload / 64);
-    auto scan = [&](size_t f0, size_t cnt) -> size_t { // frames accepted from f0 on; sets `bad` at the first bad one
-        for (size_t i = 0; i < cnt; ++i) {
-            const uint8_t *f = frames + (f0 + i) * frame_size;
-            if (f[0] != 0x7b || f[1] != 0x05) {
-                bad = PSDC_ERR_FRAME_HEADER;
-                return i;
-            }
-            if (f[2] != 1) { // unknown id, or Fls / ThermostatEem / Mpll: not AdcDac
-                bad = PSDC_ERR_FRAME_FORMAT;
-                return i;
-            }
-            if (payload % 64 != 0 || (int)f[3] != batches) {
-                bad = PSDC_ERR_FRAME_SIZE;
-                return i;
-            }
-            const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
-            h->loss.received += f[3];
-            if (h->loss.have_seq)
-                h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
-            h->loss.next_seq = seq + f[3];                              // wrapping_add
-            h->loss.have_seq = 1;
+    size_t f0 = 0;
+    while (f0 < n_frames && bad == PSDC_OK) {
+        // the run's format: its first frame's (Header::parse, src/de/frame.rs:25-37)
+        const uint8_t *first = frames + f0 * frame_size;
+        if (first[0] != 0x7b || first[1] != 0x05) {
+            bad = PSDC_ERR_FRAME_HEADER;
+            break;
         }
-        return cnt;
-    };
-    if (batches == 0) {
-        good = scan(0, n_frames); // header-only frames carry no samples
-    } else {
+        const WireFmt *wf = wire_fmt(first[2]);
+        if (!wf || (adcdac_only && wf->id != 1)) { // unknown id -- or Fls / ThermostatEem / Mpll where only AdcDac is asked for
+            bad = PSDC_ERR_FRAME_FORMAT;
+            break;
+        }
+        if ((int)h->n_channels < wf->ntr) {
+            if (n_ok)
+                *n_ok = good;
+            return fail(h, PSDC_ERR_ARG, "the frames carry more traces than the handle has channels");
+        }
+        const int ntr = wf->ntr;
+        const int batches = (int)(payload / wf->batch_bytes);
+        bool run_end = false; // a frame of another (valid) format: the next run starts there
+        // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25, 91-93, 149-150, 173-174) and keep the loss
+        // counters (Loss::update, src/loss.rs:11-26), piece by piece inside the upload loop below so
+        // that the scan of one piece runs while the piece before it is on the link
+        auto scan = [&](size_t fa, size_t cnt) -> size_t { // frames accepted from fa on; sets `bad` at the first bad one
+            for (size_t i = 0; i < cnt; ++i) {
+                const uint8_t *f = frames + (fa + i) * frame_size;
+                if (f[0] != 0x7b || f[1] != 0x05) {
+                    bad = PSDC_ERR_FRAME_HEADER;
+                    return i;
+                }
+                if (f[2] != wf->id) {
+                    if (!adcdac_only && wire_fmt(f[2])) {
+                        run_end = true;
+                        return i;
+                    }
+                    bad = PSDC_ERR_FRAME_FORMAT; // unknown id (or, for psdc_process_adcdac_frames, not AdcDac)
+                    return i;
+                }
+                if (payload % wf->batch_bytes != 0 || (int)f[3] != batches) {
+                    bad = PSDC_ERR_FRAME_SIZE;
+                    return i;
+                }
+                const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+                h->loss.received += f[3];
+                if (h->loss.have_seq)
+                    h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
+                h->loss.next_seq = seq + f[3];                              // wrapping_add
+                h->loss.have_seq = 1;
+            }
+            return cnt;
+        };
+        if (batches == 0) {
+            const size_t cnt = scan(f0, n_frames - f0); // header-only frames carry no samples
+            good += cnt;
+            f0 += cnt;
+            continue;
+        }
         // order behind anything pending on these channels
         bool pend = false;
-        for (int ci = 0; ci < 4; ++ci)
+        for (int ci = 0; ci < ntr; ++ci)
             pend = pend || h->ch[ci].has_span() || h->ch[ci].submitted || h->ch[ci].fill;
         if (pend) {
             rc = flush_all(h);
@@ -2230,7 +2276,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
             h->frames_cap = piece_bytes;
         }
         h->idle = false;
-        for (size_t f0 = 0; f0 < n_frames && bad == PSDC_OK; f0 += piece_frames) {
+        while (f0 < n_frames && bad == PSDC_OK && !run_end) {
             const size_t cnt = scan(f0, std::min(piece_frames, n_frames - f0));
             good += cnt;
             if (cnt == 0)
@@ -2253,9 +2299,9 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
                 return rc;
             h->frames_ev_pending[b] = true;
             h->frames_cur = b ^ 1;
-            const size_t per_ch = cnt * (size_t)batches * 8;
-            float *dst[4];
-            for (int ci = 0; ci < 4; ++ci) {
+            const size_t per_ch = cnt * (size_t)batches * (size_t)wf->spb;
+            float *dst[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int ci = 0; ci < ntr; ++ci) {
                 Channel &c = h->ch[ci];
                 if (c.st.empty()) {
                     rc = add_stage(h, c);
@@ -2271,14 +2317,16 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
             rc = wait_uploads(h); // the decode kernel reads what the copy stream is bringing
             if (rc)
                 return rc;
-            HIPCHK(h, launch_adcdac(h->d_frames[b], frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3],
-                                    h->stream));
+            if (wf->id == 1)
+                HIPCHK(h, launch_adcdac(h->d_frames[b], frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3], h->stream));
+            else
+                HIPCHK(h, launch_payload(wf->id, h->d_frames[b], frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3], h->stream));
             // the device image d_frames[b] is written again two pieces later: that upload waits for this
             if (!h->frames_dec_ev[b])
                 HIPCHK(h, hipEventCreateWithFlags(&h->frames_dec_ev[b], hipEventDisableTiming));
             HIPCHK(h, hipEventRecord(h->frames_dec_ev[b], h->stream));
             h->frames_dec_pending[b] = true;
-            for (int ci = 0; ci < 4; ++ci) {
+            for (int ci = 0; ci < ntr; ++ci) {
                 h->ch[ci].st[0].total += per_ch;
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
                 h->ch[ci].submitted = true;
@@ -2286,6 +2334,7 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
             rc = advance(h);
             if (rc)
                 return rc;
+            f0 += cnt;
         }
     }
     if (n_ok)
@@ -2293,9 +2342,20 @@ int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t fra
     if (bad != PSDC_OK)
         return fail(h, bad,
                     bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
-                    : bad == PSDC_ERR_FRAME_FORMAT ? "Unknown or non-AdcDac format ID"
+                    : bad == PSDC_ERR_FRAME_FORMAT ? (adcdac_only ? "Unknown or non-AdcDac format ID" : "Unknown format ID")
                                                    : "Payload size");
     return PSDC_OK;
+}
+} // namespace
+
+int psdc_process_adcdac_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size, size_t n_frames, size_t *n_ok)
+{
+    return ingest_frames_host(h, true, frames, frame_size, n_frames, n_ok);
+}
+
+int psdc_process_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size, size_t n_frames, size_t *n_ok)
+{
+    return ingest_frames_host(h, false, frames, frame_size, n_frames, n_ok);
 }
 
 int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size, size_t n_frames,

@@ -230,6 +230,7 @@ impl<const N: usize> Drop for PsdCascade<N> {
 
 extern "C" {
     fn psdc_process_adcdac_frames(h: *mut PsdcHandle, frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
+    fn psdc_process_frames(h: *mut PsdcHandle, frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
 }
 
 pub struct PsdBank<const N: usize> {
@@ -267,6 +268,13 @@ impl<const N: usize> PsdBank<N> {
     pub fn process_adcdac_frames(&mut self, frames: &[u8], frame_size: usize) -> Result<usize, i32> {
         let mut ok = 0usize;
         let rc = unsafe { psdc_process_adcdac_frames(self.h.as_ptr(), frames.as_ptr(), frame_size, frames.len() / frame_size, &mut ok) };
+        if rc < 0 { Err(rc) } else { Ok(ok) }
+    }
+    /// the same for any of the four `Format`s (src/de/mod.rs:12-17: `AdcDac`, `Fls`, `ThermostatEem`, `Mpll`), each frame's header
+    /// naming its own: trace `i` of `Payload::traces()` lands in trace `i` of the bank, as `dec[i]` in src/bin/psd.rs:174-182.
+    pub fn process_frames(&mut self, frames: &[u8], frame_size: usize) -> Result<usize, i32> {
+        let mut ok = 0usize;
+        let rc = unsafe { psdc_process_frames(self.h.as_ptr(), frames.as_ptr(), frame_size, frames.len() / frame_size, &mut ok) };
         if rc < 0 { Err(rc) } else { Ok(ok) }
     }
     /// `PsdCascade::psd` of trace `i`

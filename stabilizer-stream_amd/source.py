@@ -5,7 +5,7 @@ feeders a GPU path needs.
 trace, with the reference's own granularity (`Data::Raw`: at most 2048 bytes = 512 samples per call,
 src/source.rs:150-157; `Data::File`: one frame of `frame_size` bytes per call, :136-142; `--repeat` wraps
 at EOF, :143-145,152-155).  At 10 GS/s that granularity would mean 2e7 calls/s, so `feed()` reads MB-scale
-spans of the SAME byte formats and hands them to `psdc_process` / `psdc_process_adcdac_frames` in bulk:
+spans of the SAME byte formats and hands them to `psdc_process` / `psdc_process_frames` in bulk:
 the cascade's result depends only on the concatenated stream, so both ways give the same PSD.
 
 UDP, the noise generator and the DSM source are host I/O outside the accelerated path.
@@ -66,7 +66,7 @@ class Source:
                     self._f.seek(0)
                     continue
                 raise EOFError  # read_exact: UnexpectedEof (src/source.rs:137-146)
-            seq, batches, traces = decode_adcdac_frame(buf)
+            _, seq, batches, traces = decode_frame(buf)
             self.received += batches  # Loss::update (src/loss.rs:11-26)
             if self._seq is not None:
                 self.dropped += (seq - self._seq) & 0xFFFFFFFF
@@ -94,7 +94,7 @@ class Source:
                 self._f.seek(0)
                 return self.feed(bank, max_bytes, channel)
             return 0
-        bank.process_adcdac_frames(buf[:nframes * fs], fs)
+        bank.process_frames(buf[:nframes * fs], fs)
         return nframes * fs
 
     def finish(self):
@@ -103,26 +103,57 @@ class Source:
         return (self.dropped / tot) if self.received else 0.0
 
 
-def decode_adcdac_frame(buf):
-    """Frame::from_bytes + AdcDac::traces on the host (src/de/frame.rs:25-60, src/de/data.rs:11-82).
-    Only used by the reference-granularity `get()` path; bulk ingest decodes on the device."""
+def decode_frame(buf):
+    """Frame::from_bytes + Payload::traces on the host for the four formats (src/de/frame.rs:25-60, src/de/data.rs:11-212).
+    Only used by the reference-granularity `get()` path; bulk ingest decodes on the device (psdc_process_frames).
+    Returns (format id, seq, batches, [(name, f32 array), ...])."""
     if len(buf) < 8:
         raise ValueError("frame shorter than its header")
     if buf[0] != 0x7B or buf[1] != 0x05:
         raise ValueError("Invalid frame header")
-    if buf[2] != 1:
-        raise ValueError("Unknown format ID" if not 1 <= buf[2] <= 4 else "not an AdcDac frame")
+    fmt = buf[2]
+    if not 1 <= fmt <= 4:
+        raise ValueError("Unknown format ID")
     batches = buf[3]
     seq = int.from_bytes(buf[4:8], "little")
-    pay = np.frombuffer(buf[8:], dtype="<i2")
-    if (len(buf) - 8) % 64 or (len(buf) - 8) // 64 != batches:
+    bb = (64, 56, 80, 24)[fmt - 1]  # bytes per batch (src/de/data.rs:13, 86, 144, 168)
+    if (len(buf) - 8) % bb or (len(buf) - 8) // bb != batches:
         raise ValueError("Payload size")
-    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)  # src/de/data.rs:28-35
-    d = pay.reshape(batches, 4, 8)
-    out = []
-    for c, name in enumerate(("ADC0", "ADC1", "DAC0", "DAC1")):
-        v = d[:, c, :].reshape(-1)
-        if c >= 2:  # i16.wrapping_add(i16::MIN) (src/de/data.rs:64,75)
-            v = (v.astype(np.int32) + 32768 + 32768) % 65536 - 32768
-        out.append((name, v.astype(np.float32) * lsb))
+    f32 = np.float32
+    if fmt == 1:
+        pay = np.frombuffer(buf[8:], dtype="<i2")
+        lsb = f32(4.096) * f32(2.5) / f32(32768)  # src/de/data.rs:28-35
+        d = pay.reshape(batches, 4, 8)
+        out = []
+        for c, name in enumerate(("ADC0", "ADC1", "DAC0", "DAC1")):
+            v = d[:, c, :].reshape(-1)
+            if c >= 2:  # i16.wrapping_add(i16::MIN) (src/de/data.rs:64,75)
+                v = (v.astype(np.int32) + 32768 + 32768) % 65536 - 32768
+            out.append((name, v.astype(np.float32) * lsb))
+        return fmt, seq, batches, out
+    w = np.frombuffer(buf[8:], dtype="<i4").reshape(batches, bb // 4)
+    hyp = lambda a, b: np.sqrt(a.astype(f32) * a.astype(f32) + b.astype(f32) * b.astype(f32))  # powi(2) + powi(2), sqrt: all f32
+    two31, two32 = f32(2147483648.0), f32(4294967296.0)  # i32::MAX as f32, (1u64 << 32) as f32
+    tau = f32(6.283185307179586)
+    if fmt == 2:  # Fls (src/de/data.rs:97-139)
+        ph = (w[:, 2].astype(np.int64) & 0xFFFFFFFF) | (w[:, 3].astype(np.int64) << 32)  # b[0][2..4] as one i64
+        return fmt, seq, batches, [
+            ("AR", hyp(w[:, 0], w[:, 1]) * (f32(1.0) / two31)),
+            ("AP", ph.astype(f32) * (tau / f32(65536.0))),
+            ("BI", w[:, 7].astype(f32) / two31),
+            ("BQ", w[:, 8].astype(f32) / two31)]
+    if fmt == 3:  # ThermostatEem (src/de/data.rs:154-163)
+        f = np.frombuffer(buf[8:], dtype="<f4").reshape(batches, 20)
+        return fmt, seq, batches, [(name, f[:, i].astype(f32)) for name, i in zip(("T00", "T20", "I0", "I1"), (0, 8, 13, 16))]
+    return fmt, seq, batches, [  # Mpll (src/de/data.rs:178-211)
+        ("phase (rad)", w[:, 4].astype(f32) * (tau / two32)),
+        ("frequency (kHz)", w[:, 5].astype(f32) * (f32(1.0) / f32(1.28e-3) / two32)),
+        ("amplitude (V/G10)", hyp(w[:, 0], w[:, 1]) * (f32(10.24) / f32(10.0) * f32(2.0) * f32(2.0) / two32))]
+
+
+def decode_adcdac_frame(buf):
+    """decode_frame restricted to AdcDac: (seq, batches, traces)."""
+    if len(buf) >= 3 and buf[0] == 0x7B and buf[1] == 0x05 and 2 <= buf[2] <= 4:
+        raise ValueError("not an AdcDac frame")
+    _, seq, batches, out = decode_frame(buf)
     return seq, batches, out

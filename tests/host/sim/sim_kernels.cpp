@@ -455,6 +455,28 @@ hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_fram
     return hipSuccess;
 }
 
+// ---- payload_kernel (Fls / ThermostatEem / Mpll): every payload byte is read, one sample per batch and trace written.  No scenario
+// of round_plan_check feeds these formats (their ingest shares ingest_frames_host with AdcDac, which the frames scenario drives):
+// the model keeps the link complete and the accesses honest.
+hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, float *d0, float *d1, float *d2,
+                          float *d3, hipStream_t s)
+{
+    sim::enqueue(s, [=] {
+        const size_t bb = fmt == 2 ? 56 : fmt == 3 ? 80 : 24;
+        float *dst[4] = {d0, d1, d2, d3};
+        for (size_t f = 0; f < n_frames; ++f)
+            for (int b = 0; b < batches; ++b) {
+                const uint8_t *p = frames + f * frame_size + 8 + (size_t)b * bb;
+                unsigned acc = 0;
+                for (size_t i = 0; i < bb; ++i)
+                    acc += p[i];
+                for (int ch = 0; ch < (fmt == 4 ? 3 : 4); ++ch)
+                    dst[ch][f * (size_t)batches + (size_t)b] = (float)(acc & 1);
+            }
+    });
+    return hipSuccess;
+}
+
 // ---- adcdac_verdict_kernel: Header::parse + the AdcDac size checks + Loss::update, as the kernel defines its four words --
 hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok, int check,
                                  size_t n_loss, unsigned long long *acc, unsigned long long *host_out, hipStream_t s)

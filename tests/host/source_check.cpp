@@ -115,6 +115,52 @@ int main(int argc, char **argv)
         if (!threw)
             ++bad;
     }
+    { // the other three payload formats (src/de/data.rs:84-212): one file per format, five batches of pseudo-random bytes a frame;
+      // the decoded traces are printed as bit patterns -- tests/test_host_logic.py holds them to the oracle's decode bit for bit
+        for (int fmt = 2; fmt <= 4; ++fmt) {
+            const size_t bb = fmt == 2 ? 56 : fmt == 3 ? 80 : 24;
+            const uint32_t batches = 5;
+            const size_t fs = 8 + bb * batches;
+            const std::string path = dir + "/fmt" + std::to_string(fmt) + ".bin";
+            std::FILE *f = std::fopen(path.c_str(), "wb");
+            uint32_t lcg = 12345u * (uint32_t)fmt;
+            for (int k = 0; k < 2; ++k) {
+                std::vector<uint8_t> fr(fs);
+                fr[0] = 0x7b, fr[1] = 0x05, fr[2] = (uint8_t)fmt, fr[3] = (uint8_t)batches;
+                const uint32_t seq = 100u * (uint32_t)fmt + batches * (uint32_t)k;
+                for (int b = 0; b < 4; ++b)
+                    fr[4 + b] = (uint8_t)(seq >> (8 * b));
+                for (size_t i = 8; i < fs; ++i) {
+                    lcg = lcg * 1664525u + 1013904223u;
+                    fr[i] = (uint8_t)(lcg >> 24);
+                }
+                std::fwrite(fr.data(), 1, fs, f);
+            }
+            std::fclose(f);
+            SourceOpts o;
+            o.file = path;
+            o.frame_size = fs;
+            Source s(o);
+            Traces t;
+            int k = 0;
+            while (s.get(t)) {
+                if (t.size() != (fmt == 4 ? 3u : 4u))
+                    ++bad;
+                for (size_t c = 0; c < t.size(); ++c) {
+                    std::printf("fmt %d frame %d trace %zu [%s]:", fmt, k, c, t[c].first);
+                    for (float v : t[c].second) {
+                        uint32_t u;
+                        std::memcpy(&u, &v, 4);
+                        std::printf(" %08x", u);
+                    }
+                    std::printf("\n");
+                }
+                ++k;
+            }
+            if (k != 2 || s.received() != 2 * batches || s.dropped() != 0)
+                ++bad;
+        }
+    }
     std::printf(bad ? "FAIL\n" : "OK\n");
     return bad ? 1 : 0;
 }

@@ -79,7 +79,7 @@ def test_round_planner_on_the_cpu_under_sanitizers():
     assert "every segment and every decimator output exactly once" in r.stdout
 
 
-def test_cpp_source_mirror(pkg, tmp_path):
+def test_cpp_source_mirror(pkg, ora, tmp_path):
     """cpp/source.hpp, the C++ mirror of the reference's file-backed Source (src/source.rs:135-157): get() at the
     reference's granularity (512 raw samples / one frame per call, --repeat wrap), AdcDac decode on the host
     (src/de/data.rs:11-82), Loss counting (src/loss.rs:11-26), de::Error text -- tests/host/source_check.cpp, CPU only."""
@@ -88,6 +88,25 @@ def test_cpp_source_mirror(pkg, tmp_path):
     r = subprocess.run([os.path.join(host, "source_check"), str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
     assert "3112 with --repeat" in r.stdout and "6 dropped" in r.stdout
+    # Fls / ThermostatEem / Mpll (src/de/data.rs:84-212): the C++ decode of the program's pseudo-random frames against the oracle's,
+    # bit for bit (the frames are rebuilt here with the same generator)
+    import struct
+    seen = 0
+    for fmt, bb in ((2, 56), (3, 80), (4, 24)):
+        lcg = (12345 * fmt) & 0xFFFFFFFF
+        for k in range(2):
+            pay = bytearray()
+            for _ in range(bb * 5):
+                lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+                pay.append(lcg >> 24)
+            fr = bytes([0x7B, 0x05, fmt, 5]) + struct.pack("<I", 100 * fmt + 5 * k) + bytes(pay)
+            st, f, seq, bat, tr = ora.frame_decode(fr)
+            assert (st, f, seq, bat) == (0, fmt, 100 * fmt + 5 * k, 5)
+            for c, (name, v) in enumerate(tr):
+                want = f"fmt {fmt} frame {k} trace {c} [{name}]:" + "".join(f" {u:08x}" for u in v.view(np.uint32))
+                assert want in r.stdout, want
+                seen += 1
+    assert seen == 2 * (4 + 4 + 3)
 
 
 def test_cpp_mirror_builds_against_the_abi(pkg):
