@@ -1,4 +1,5 @@
 """Feed side: the reference's file formats through the Source mirror."""
+import os
 import numpy as np
 import pytest
 
@@ -104,3 +105,24 @@ def test_feeders_on_gpu(pkg, ora, gpu_required, tmp_path):
     bulk.close()
     small.close()
     g.close()
+
+
+def test_stream_to_raw_tool(pkg, ora, tmp_path):
+    """tools/stream_to_raw.py = src/bin/stream_to_raw.rs over `Source.get()`: trace 2 of a Mpll frame file comes out as the f32 file
+    `--raw` reads back (the oracle's decode of the same frames, bit for bit)."""
+    import struct
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    nb, fs = 60, 8 + 24 * 60
+    frames = b"".join(bytes([0x7B, 0x05, 4, nb]) + struct.pack("<I", k * nb) + rng.integers(0, 256, size=24 * nb, dtype=np.uint8).tobytes()
+                      for k in range(7))
+    p = tmp_path / "mpll.bin"
+    p.write_bytes(frames)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_to_raw.py"), "--file", str(p), "--frame-size", str(fs),
+                        "--trace", "2"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = np.concatenate([ora.frame_decode(frames[k * fs:(k + 1) * fs])[4][2][1] for k in range(7)])
+    got = np.frombuffer(r.stdout, dtype="<f4")
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
