@@ -247,6 +247,13 @@ int psdc_process_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size
 int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size,
                                       size_t n_frames, size_t *n_ok);
 
+/* psdc_process_frames for frames that already sit in device memory: any of the four formats, in runs.  The headers (8 of every
+ * frame_size bytes) come to the host in one strided copy and are validated there; the payloads stay on the device -- Fls /
+ * ThermostatEem / Mpll runs are decoded straight from `d_frames` into the stage-0 streams, AdcDac runs take
+ * psdc_process_adcdac_frames_device (whose lifetime, ordering and alignment rules apply to the whole call: d_frames valid and
+ * unmodified until psdc_sync() / a read-out / a psdc_record_consumed event, its producer COMPLETED before the call). */
+int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size, size_t n_frames, size_t *n_ok);
+
 /* Loss (src/loss.rs:3-26): sequence-gap accounting over the frames ingested by
  * psdc_process_frames / psdc_process_adcdac_frames[_device].  received counts batches; dropped the batches missing
  * between consecutive frames (u32 wrapping_sub); gaps are counted, never zero-filled. */

@@ -270,6 +270,7 @@ def lib():
     f("psdc_record_consumed", i32, [H, C.c_void_p])
     f("psdc_process_adcdac_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_process_frames", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
+    f("psdc_process_frames_device", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_process_adcdac_frames_device", i32, [H, C.c_void_p, sz, sz, C.POINTER(sz)])
     f("psdc_loss_read", i32, [H, C.POINTER(_CLoss), i32])
     f("psdc_flush", i32, [H])
@@ -313,7 +314,7 @@ def lib():
 EXPORTS = [
     "psdc_abi_version", "psdc_last_error", "psdc_create", "psdc_destroy", "psdc_clone", "psdc_reset",
     "psdc_configure", "psdc_set_detrend", "psdc_set_avg", "psdc_process", "psdc_process_device",
-    "psdc_process_adcdac_frames", "psdc_process_frames", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
+    "psdc_process_adcdac_frames", "psdc_process_frames", "psdc_process_frames_device", "psdc_loss_read", "psdc_flush", "psdc_sync", "psdc_num_stages", "psdc_stage_info",
     "psdc_stage_spectrum", "psdc_stage_gain", "psdc_stage_buf", "psdc_read_channel", "psdc_psd", "psdc_rbw",
     "psdc_frequencies", "psdc_hbf_response_length", "psdc_stitch", "psdc_plan_counts",
     "psdc_var_eval", "psdc_hbf_dec8", "psdc_fill_noise_device", "psdc_profile_read",
@@ -448,6 +449,14 @@ class PsdCascadeBank:
         buf = np.frombuffer(data, dtype=np.uint8)
         ok = C.c_size_t(0)
         rc = self._L.psdc_process_frames(self._h, buf.ctypes.data_as(C.c_void_p), frame_size, buf.size // frame_size, C.byref(ok))
+        if rc < 0:
+            _raise(rc, self._h)
+        return ok.value
+
+    def process_frames_device(self, ptr, frame_size, n_frames):
+        """process_frames for frames resident in device memory at address `ptr`; returns the number of frames ingested."""
+        ok = C.c_size_t(0)
+        rc = self._L.psdc_process_frames_device(self._h, C.c_void_p(ptr), frame_size, n_frames, C.byref(ok))
         if rc < 0:
             _raise(rc, self._h)
         return ok.value

@@ -678,12 +678,15 @@ __global__ __launch_bounds__(256) void payload_kernel(const uint8_t *__restrict_
                                                       float *d0, float *d1, float *d2, float *d3)
 {
     constexpr int BB = payload_fmt(FMT).batch_bytes;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(frames) | frame_size) & 3u) == 0;
     const size_t total = n_frames * (size_t)batches;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
         const size_t f = g / (size_t)batches, b = g % (size_t)batches;
         const uint8_t *p = frames + f * frame_size + 8 + b * BB;
-        auto word = [&](int i) { // u32::from_le_bytes of word i of the batch (any base alignment)
-            const uint8_t *q = p + 4 * i;
+        auto word = [&](int i) { // u32::from_le_bytes of word i of the batch: one load when the frames are 4-byte aligned (every valid
+            const uint8_t *q = p + 4 * i; // frame_size is a multiple of 8; the base is the caller's), bytes otherwise
+            if (aligned)
+                return *reinterpret_cast<const uint32_t *>(q);
             return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
         };
         auto i32f = [&](int i) { return (float)(int32_t)word(i); }; // i32::from_le_bytes(..) as f32

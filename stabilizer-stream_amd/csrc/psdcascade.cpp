@@ -2561,6 +2561,150 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
     return PSDC_OK;
 }
 
+// psdc_process_frames for frames that already sit in device memory.  The headers (8 of every frame_size bytes) come to the host in ONE
+// strided copy and are validated there exactly as ingest_frames_host does; the payloads never leave the device: runs of Fls /
+// ThermostatEem / Mpll frames are decoded by payload_kernel straight from the caller's buffer into the stage-0 streams, runs of AdcDac
+// frames go through psdc_process_adcdac_frames_device (read in place where a fused kernel exists).
+int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t frame_size, size_t n_frames, size_t *n_ok)
+{
+    if (n_ok)
+        *n_ok = 0;
+    int rc = check_channel(h, 0);
+    if (rc)
+        return rc;
+    ON_DEVICE(h, h->device);
+    if (n_frames == 0)
+        return PSDC_OK;
+    if (!d_frames)
+        return fail(h, PSDC_ERR_ARG, "null input");
+    if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
+        return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
+    std::vector<uint8_t> hdr;
+    try {
+        hdr.resize(8 * n_frames);
+    } catch (const std::bad_alloc &) {
+        return fail(h, PSDC_ERR_NOMEM, "header copy");
+    }
+    // (a copy on the null stream: the handle's streams are non-blocking, it waits for none of their work)
+    HIPCHK(h, hipMemcpy2D(hdr.data(), 8, d_frames, frame_size, 8, n_frames, hipMemcpyDeviceToHost));
+    const size_t payload = frame_size - 8;
+    size_t good = 0, f0 = 0;
+    int bad = PSDC_OK;
+    auto done = [&](int code) {
+        if (n_ok)
+            *n_ok = good;
+        return code == PSDC_OK ? PSDC_OK
+                               : fail(h, code,
+                                      code == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
+                                      : code == PSDC_ERR_FRAME_FORMAT ? "Unknown format ID"
+                                                                      : "Payload size");
+    };
+    while (f0 < n_frames) {
+        const uint8_t *first = hdr.data() + 8 * f0;
+        if (first[0] != 0x7b || first[1] != 0x05)
+            return done(PSDC_ERR_FRAME_HEADER);
+        const WireFmt *wf = wire_fmt(first[2]);
+        if (!wf)
+            return done(PSDC_ERR_FRAME_FORMAT);
+        if ((int)h->n_channels < wf->ntr) {
+            if (n_ok)
+                *n_ok = good;
+            return fail(h, PSDC_ERR_ARG, "the frames carry more traces than the handle has channels");
+        }
+        if (wf->id == 1) { // a run of AdcDac frames: its own entry point checks them (and counts their Loss) on the device
+            size_t run = 1;
+            while (f0 + run < n_frames && hdr[8 * (f0 + run)] == 0x7b && hdr[8 * (f0 + run) + 1] == 0x05 && hdr[8 * (f0 + run) + 2] == 1)
+                ++run;
+            size_t ok = 0;
+            rc = psdc_process_adcdac_frames_device(h, d_frames + f0 * frame_size, frame_size, run, &ok);
+            good += ok;
+            if (rc) {
+                if (n_ok)
+                    *n_ok = good;
+                return rc;
+            }
+            f0 += run;
+            continue;
+        }
+        const int ntr = wf->ntr;
+        const int batches = (int)(payload / wf->batch_bytes);
+        // order behind anything pending on these channels (held spans, host-fed samples)
+        bool pend = false;
+        for (int ci = 0; ci < ntr; ++ci)
+            pend = pend || h->ch[ci].has_span() || h->ch[ci].submitted || h->ch[ci].fill;
+        if (pend) {
+            rc = flush_all(h);
+            if (rc)
+                return rc;
+        }
+        // pieces of ~2^22 samples per trace: a stage-0 stream buffer never grows by more than that at once
+        const size_t piece_frames = std::max<size_t>(1, ((size_t)1 << 22) / (size_t)std::max(1, batches));
+        bool run_end = false;
+        while (f0 < n_frames && bad == PSDC_OK && !run_end) {
+            size_t cnt = 0;
+            const size_t lim = std::min(piece_frames, n_frames - f0);
+            for (; cnt < lim; ++cnt) { // Header::parse + the payload's size checks + Loss::update, as ingest_frames_host's scan
+                const uint8_t *f = hdr.data() + 8 * (f0 + cnt);
+                if (f[0] != 0x7b || f[1] != 0x05) {
+                    bad = PSDC_ERR_FRAME_HEADER;
+                    break;
+                }
+                if (f[2] != wf->id) {
+                    if (wire_fmt(f[2]))
+                        run_end = true;
+                    else
+                        bad = PSDC_ERR_FRAME_FORMAT;
+                    break;
+                }
+                if (payload % wf->batch_bytes != 0 || (int)f[3] != batches) {
+                    bad = PSDC_ERR_FRAME_SIZE;
+                    break;
+                }
+                const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+                h->loss.received += f[3];
+                if (h->loss.have_seq)
+                    h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
+                h->loss.next_seq = seq + f[3];                              // wrapping_add
+                h->loss.have_seq = 1;
+            }
+            good += cnt;
+            if (cnt == 0)
+                break;
+            if (batches > 0) {
+                const size_t per_ch = cnt * (size_t)batches;
+                float *dst[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int ci = 0; ci < ntr; ++ci) {
+                    Channel &c = h->ch[ci];
+                    if (c.st.empty()) {
+                        rc = add_stage(h, c);
+                        if (rc)
+                            return rc;
+                    }
+                    StageState &s0 = c.st[0];
+                    rc = ensure_room(h, s0, s0.total + per_ch);
+                    if (rc)
+                        return rc;
+                    dst[ci] = s0.buf.p[s0.buf.cur] + (s0.total - s0.buf.base);
+                }
+                HIPCHK(h, launch_payload(wf->id, d_frames + f0 * frame_size, frame_size, cnt, batches, dst[0], dst[1], dst[2], dst[3], h->stream));
+                h->idle = false;
+                for (int ci = 0; ci < ntr; ++ci) {
+                    h->ch[ci].st[0].total += per_ch;
+                    h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
+                    h->ch[ci].submitted = true;
+                }
+                rc = advance(h);
+                if (rc)
+                    return rc;
+            }
+            f0 += cnt;
+        }
+        if (bad != PSDC_OK)
+            return done(bad);
+    }
+    return done(PSDC_OK);
+}
+
 int psdc_record_consumed(psdc_handle *h, void *consumed_event)
 {
     if (!h || !consumed_event)

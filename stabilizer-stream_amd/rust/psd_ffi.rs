@@ -231,6 +231,7 @@ impl<const N: usize> Drop for PsdCascade<N> {
 extern "C" {
     fn psdc_process_adcdac_frames(h: *mut PsdcHandle, frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
     fn psdc_process_frames(h: *mut PsdcHandle, frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
+    fn psdc_process_frames_device(h: *mut PsdcHandle, d_frames: *const u8, frame_size: usize, n_frames: usize, n_ok: *mut usize) -> c_int;
 }
 
 pub struct PsdBank<const N: usize> {
@@ -275,6 +276,16 @@ impl<const N: usize> PsdBank<N> {
     pub fn process_frames(&mut self, frames: &[u8], frame_size: usize) -> Result<usize, i32> {
         let mut ok = 0usize;
         let rc = unsafe { psdc_process_frames(self.h.as_ptr(), frames.as_ptr(), frame_size, frames.len() / frame_size, &mut ok) };
+        if rc < 0 { Err(rc) } else { Ok(ok) }
+    }
+    /// `process_frames` for `n_frames` frames that already sit in device memory at `d_frames` (valid and unmodified until `sync()`
+    /// or a read-out; see include/psdcascade.h).
+    ///
+    /// # Safety
+    /// `d_frames` must point to `n_frames * frame_size` readable bytes of device memory on the bank's device.
+    pub unsafe fn process_frames_device(&mut self, d_frames: *const u8, frame_size: usize, n_frames: usize) -> Result<usize, i32> {
+        let mut ok = 0usize;
+        let rc = psdc_process_frames_device(self.h.as_ptr(), d_frames, frame_size, n_frames, &mut ok);
         if rc < 0 { Err(rc) } else { Ok(ok) }
     }
     /// `PsdCascade::psd` of trace `i`

@@ -156,6 +156,13 @@ inline hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyK
     memmove(dst, src, bytes);
     return hipSuccess;
 }
+// (a null-stream copy does NOT wait for the handle's non-blocking streams: nothing is drained here -- what it reads is the caller's)
+inline hipError_t hipMemcpy2D(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind)
+{
+    for (size_t r = 0; r < height; ++r)
+        memmove(static_cast<char *>(dst) + r * dpitch, static_cast<const char *>(src) + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s)
 {
     sim::enqueue(s, [=] { memset(dst, v, bytes); });

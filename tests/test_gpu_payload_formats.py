@@ -193,3 +193,56 @@ def test_source_feeds_a_frame_file_of_any_format(pkg, ora, gpu_required, tmp_pat
     for i in range(3):
         check_against_oracle(pkg, ora, g, [want[i]], n, channel=i, what=f"Source.feed Mpll trace {i}")
     g.close()
+
+
+def test_frames_resident_in_device_memory(pkg, ora, gpu_required):
+    """psdc_process_frames_device: the same runs of AdcDac / Fls / Mpll frames (frame size 8 + 1344) from a device buffer -- the headers
+    go to the host in one strided copy, Fls / Mpll payloads are decoded from the caller's buffer, the AdcDac runs are read in place by
+    the fused kernels (N = 1024) -- against the oracle, and against the host-memory call (same Loss, same pending samples bit for bit);
+    then the de::Error of a bad frame in the middle of a device-resident Mpll run."""
+    import torch
+    n = 1024
+    rng = np.random.default_rng(44)
+    parts, seq = [], 3
+    for fmt, batches, nframes in ((2, 24, 300), (1, 21, 500), (4, 56, 200), (1, 21, 90), (2, 24, 1)):
+        if fmt == 1:
+            pay = [rng.integers(-3000, 3000, size=batches * 32).astype("<i2").tobytes() for _ in range(nframes)]
+        else:
+            pay = random_payloads(rng, fmt, batches, nframes, wild=False)
+        d, fs = make_frames(fmt, batches, pay, seq0=seq)
+        parts.append(d)
+        seq += nframes * batches + (5 if fmt == 4 else 0)
+    data = b"".join(parts)
+    nf = len(data) // fs
+    dev = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 4)
+    cut = 450  # inside the first AdcDac run
+    assert g.process_frames_device(dev.data_ptr(), fs, cut) == cut
+    assert g.process_frames_device(dev.data_ptr() + cut * fs, fs, nf - cut) == nf - cut
+    g.sync()
+    want = oracle_traces(ora, data, fs)
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [want[c]], n, channel=c, what=f"device-resident mixed formats, cascade {c}")
+    gh = pkg.PsdCascadeBank(n, 4)
+    assert gh.process_frames(data, fs) == nf
+    assert g.loss() == gh.loss() == {"received": 301 * 24 + 590 * 21 + 200 * 56, "dropped": 5}
+    for c in range(4):
+        assert np.array_equal(g.stage_buf(c, 0).view(np.uint32), gh.stage_buf(c, 0).view(np.uint32))
+    gh.close()
+    g.close()
+    # a bad frame inside a device-resident run
+    d4, fs4 = make_frames(4, 60, random_payloads(rng, 4, 60, 40, wild=False))
+    for pos, val, code in ((0, 0x00, pkg.ERR_FRAME_HEADER), (2, 9, pkg.ERR_FRAME_FORMAT), (3, 59, pkg.ERR_FRAME_SIZE)):
+        b = bytearray(d4)
+        b[17 * fs4 + pos] = val
+        dv = torch.from_numpy(np.frombuffer(bytes(b), dtype=np.uint8).copy()).cuda()
+        torch.cuda.synchronize()
+        g = pkg.PsdCascadeBank(256, 3)
+        with pytest.raises(pkg.FrameError) as e:
+            g.process_frames_device(dv.data_ptr(), fs4, 40)
+        assert e.value.code == code
+        w = oracle_traces(ora, d4[: 17 * fs4], fs4)
+        check_against_oracle(pkg, ora, g, [w[0]], 256, channel=0, what="frames before the bad one")
+        assert g.loss()["received"] == 17 * 60
+        g.close()

@@ -64,3 +64,16 @@ for fmt, bb, nb, name in ((4, 24, 60, "Mpll"), (3, 80, 18, "ThermostatEem"), (2,
     dt = time.perf_counter() - t0
     print(f"{name} frames (host memory, N = 1024): {reps * nfr * nb * ntr / dt / 1e6:.0f} MS/s over {ntr} traces ({len(buf) * reps / dt / 1e9:.2f} GB/s of frame bytes)")
     g3.close()
+    dv = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    g4 = pkg.PsdCascadeBank(1024, ntr)
+    g4.process_frames_device(dv.data_ptr(), fs2, nfr)
+    g4.sync()
+    reps = 40
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g4.process_frames_device(dv.data_ptr(), fs2, nfr)
+    g4.sync()
+    dt = time.perf_counter() - t0
+    print(f"{name} frames (device memory, N = 1024): {reps * nfr * nb * ntr / dt / 1e6:.0f} MS/s over {ntr} traces ({len(buf) * reps / dt / 1e9:.2f} GB/s of frame bytes)")
+    g4.close()
