@@ -186,7 +186,7 @@ def host_fed_rate(pkg, n, device, seconds=2.0):
                     "hipMemcpyAsync, kernels); link-bound"}
 
 
-def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None):
+def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None, window=None):
     """A short untimed-by-`value` leg of the same cascade at another shape: 1 channel raw f32, 2^log2_batch samples
     resident in HBM, passes until `seconds` have gone by.  Returns value + kernel-only roofline like the headline's."""
     T = 1 << log2_batch
@@ -194,7 +194,7 @@ def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None):
         buf = torch.empty(T, dtype=torch.float32, device="cuda")
         pkg.fill_noise_device(buf.data_ptr(), T, seed=0x7654321, device=device)
         torch.cuda.synchronize()
-    bank = pkg.PsdCascadeBank(n, 1, device=device)
+    bank = pkg.PsdCascadeBank(n, 1, device=device) if window is None else pkg.PsdCascadeBank(n, 1, window=window, device=device)
     for _ in range(4):
         bank.process_device(0, buf.data_ptr(), T)
     bank.sync()
@@ -213,7 +213,8 @@ def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None):
     kern_s = prof["kernel_ms"] * 1e-3
     ach = ALG_BYTES_PER_SAMPLE * prof["stage0_samples"] / kern_s / 1e9 if kern_s > 0 else 0.0
     return {"value": passes * T / dt / 1e6, "unit": "MS/s",
-            "workload": f"1-channel raw f32, PsdCascade N={n}, {passes} passes over 2^{log2_batch} samples resident in HBM ({T * 4 >> 20} MiB), {ns} stages",
+            "workload": f"1-channel raw f32, PsdCascade N={n}{'' if window is None else ', Window::rectangular() (overlap 0)'}, {passes} passes over 2^{log2_batch} samples "
+                        f"resident in HBM ({T * 4 >> 20} MiB), {ns} stages",
             "roofline": {"bound": "hbm", "binding": BINDING, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "end_to_end_frac": ALG_BYTES_PER_SAMPLE * passes * T / dt / 1e9 / HBM_PEAK_GBPS,
                          "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(1, prof["launches"])}}
@@ -636,6 +637,8 @@ def main():
             oc["cfg3_frames_device"] = side_leg_frames(pkg, torch, local_rank, args.side_seconds)
             oc["cfg5_n16384"] = side_leg_raw(pkg, torch, 16384, 26, local_rank, args.side_seconds)
             oc["cfg3_size_n4096_raw"] = side_leg_raw(pkg, torch, 4096, 26, local_rank, args.side_seconds)
+            # Window::rectangular() (src/psd.rs:24-32) at the headline's size: the fused kernels with two disjoint segments per transform
+            oc["rectangular_n1024"] = side_leg_raw(pkg, torch, 1024, 26, local_rank, args.side_seconds, window=pkg.Window.RECTANGULAR)
             out["other_configs"] = oc
             # the headline shape beyond the 256 MiB Infinity Cache (FETCH_SIZE counts fabric requests, MALL hits included)
             out["hbm_honest"] = side_leg_raw(pkg, torch, 1024, 28, local_rank, args.side_seconds)
