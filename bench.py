@@ -295,7 +295,7 @@ def side_leg_frames(pkg, torch, device, seconds, n=4096, batches=22, log2_per_tr
                          "note": "achieved = n_frames x frame_size / time of the dominant (fused) launches; end_to_end_frac over wall time"}}
 
 
-def measured_traffic(kernel, n, channels, samples):
+def measured_traffic(kernel, n, channels, samples, window="hann"):
     """HBM bytes per one-span dominant launch from the latest committed PMC passes for this workload shape
     (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of `bench.py --coalesce 1 --passes 1` under
     rocprofv3 --pmc); None if this shape was not measured."""
@@ -311,6 +311,10 @@ def measured_traffic(kernel, n, channels, samples):
         if (d.get("fft_size") or 1024) != n or (d.get("channels") or 1) != channels:
             continue
         if (d.get("samples_per_launch") or (1 << 26)) != samples * channels:
+            continue
+        # the window decides the kernel variant (overlap 0 runs the two-segment form: other traffic): a record is of the window its
+        # workload string names (the rectangular-window passes r04*_rect1024 matched the headline's shape otherwise)
+        if ("rectangular" in (d.get("workload") or "")) != (window == "rectangular"):
             continue
         best = d
     return best
@@ -574,7 +578,7 @@ def main():
         flop = ALG_FLOP_PER_SAMPLE.get(n, 5 * np.log2(n) + 18)
         kname = ("fused_kernel" if n in (256, 512, 1024) else "bigfused3_kernel" if n in (2048, 4096) else
                  "bigfused_kernel" if n in (8192, 16384) else "welch_kernel")
-        tr = measured_traffic(kname, n, C, T)
+        tr = measured_traffic(kname, n, C, T, "rectangular" if args.window == "rectangular" else "hann")
         out = {
             "metric": "MS/s ingested (PsdCascade N=%d, %s)" % (n, "AdcDac frames, samples of the four traces" if frames else "raw f32"),
             "value": msps, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

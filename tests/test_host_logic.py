@@ -363,3 +363,17 @@ def test_kernels_pass_the_machine_verifier():
     r = subprocess.run(["make", "-j8", "-C", csrc, "verify"], capture_output=True, text=True, timeout=880)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "every kernel TU clean" in r.stdout
+
+
+def test_bench_traffic_record_is_of_the_benched_window():
+    """bench.py's `roofline.traffic` is taken from the committed PMC passes of the SAME shape (profiles/*_traffic.json): the record of
+    the rectangular-window kernel (same kernel family, size, samples) must not stand in for the headline's, nor the other way round."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    hann = b.measured_traffic("fused_kernel", 1024, 1, 1 << 26)
+    rect = b.measured_traffic("fused_kernel", 1024, 1, 1 << 26, "rectangular")
+    assert hann and "Hann" in hann["workload"] and "rectangular" not in hann["workload"]
+    assert rect and "rectangular" in rect["workload"]
+    assert hann["ratio"] > rect["ratio"]  # (1.35 against 1.20: half the transforms, the same streams)

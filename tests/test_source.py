@@ -126,3 +126,46 @@ def test_stream_to_raw_tool(pkg, ora, tmp_path):
     want = np.concatenate([ora.frame_decode(frames[k * fs:(k + 1) * fs])[4][2][1] for k in range(7)])
     got = np.frombuffer(r.stdout, dtype="<f4")
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_psd_cli_tool(pkg, ora, gpu_required, tmp_path):
+    """tools/psd_cli.py = the receiver loop of src/bin/psd.rs:158-221 without the GUI: a Mpll frame file (the reference CLI's default
+    frame size) through `Source` into one PsdCascade<512> per trace with the reference's default AcqOpts (detrend mean, avg_max 1000),
+    read out as `Cmd::Send` does.  The printed integrated RMS of every trace against the oracle's cascade + Trace::plot on the oracle's
+    decode of the same frames."""
+    import struct
+    import subprocess
+    import sys
+    rng = np.random.default_rng(12)
+    nb, fs, nframes = 60, 1448, 700
+    w = rng.integers(-(1 << 31), 1 << 31, size=(nframes, nb, 6), dtype=np.int64).astype(np.int32)
+    frames = b"".join(bytes([0x7B, 0x05, 4, nb]) + struct.pack("<I", k * nb) + w[k].astype("<i4").tobytes() for k in range(nframes))
+    p = tmp_path / "mpll.bin"
+    p.write_bytes(frames)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "psd_cli.py"), "--file", str(p), "--fs", "781250", "--integrate",
+                        "--csv", str(tmp_path / "csv")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    traces = [[] for _ in range(3)]
+    for k in range(nframes):
+        st, fmt, seq, bat, tr = ora.frame_decode(frames[k * fs:(k + 1) * fs])
+        assert st == 0
+        for i, (_, v) in enumerate(tr):
+            traces[i].append(v)
+    for i, name in enumerate(("phase (rad)", "frequency (kHz)", "amplitude (V/G10)")):
+        o = ora.PsdCascade(512, "f64")
+        o.set_detrend("mean")
+        o.set_avg(999, 0xFFFFFFFE)  # AcqOpts::avg_opts: avg_max - 1, avg - 1 (src/bin/psd.rs:74-79)
+        o.process(np.concatenate(traces[i]))
+        psd, _, br = o.psd(keep_overlap=False, min_count=1, keep_transition_band=False)
+        rms, xy = ora.trace_plot(psd.astype(np.float32), o.frequencies(br), fs=781250.0, integrate=True, integral_start=1e-6 * 781250.0,
+                                 integral_end=0.5 * 781250.0)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith(name + ":")]
+        assert len(line) == 1, r.stdout
+        got = float(line[0].rsplit("rms", 1)[1])
+        assert got == pytest.approx(rms, rel=2e-5), (name, got, rms)
+        assert f"stages {o.num_stages} " in line[0] and f"bins {psd.size} " in line[0]
+        csv = np.loadtxt(tmp_path / "csv" / ("".join(ch if ch.isalnum() else "_" for ch in name) + ".csv"), delimiter=",", ndmin=2)
+        assert csv.shape == xy.shape and np.allclose(csv[:, 0], xy[:, 0], rtol=1e-6)
+    assert "loss: 0 of 42000 batches" in r.stdout
