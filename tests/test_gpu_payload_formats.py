@@ -246,3 +246,21 @@ def test_frames_resident_in_device_memory(pkg, ora, gpu_required):
         check_against_oracle(pkg, ora, g, [w[0]], 256, channel=0, what="frames before the bad one")
         assert g.loss()["received"] == 17 * 60
         g.close()
+
+
+@pytest.mark.parametrize("fmt,batches,shift", [(4, 60, 1), (2, 25, 2), (3, 18, 7)])
+def test_device_frames_at_an_unaligned_base(pkg, ora, gpu_required, fmt, batches, shift):
+    """Any base address is legal (the API takes bytes): the decode kernel then assembles its words from bytes -- same bits."""
+    import torch
+    rng = np.random.default_rng(50 + fmt)
+    nframes = 9000 // batches
+    data, fs = make_frames(fmt, batches, random_payloads(rng, fmt, batches, nframes, wild=True))
+    dev = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+    dev[shift:shift + len(data)] = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(16384, 4)
+    assert g.process_frames_device(dev.data_ptr() + shift, fs, nframes) == nframes
+    want = oracle_traces(ora, data, fs)
+    for c in range(len(pkg.TRACE_NAMES[pkg.Format(fmt)])):
+        assert np.array_equal(g.stage_buf(c, 0).view(np.uint32), want[c].view(np.uint32))
+    g.close()
