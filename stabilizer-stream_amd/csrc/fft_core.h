@@ -264,10 +264,31 @@ PSDK_HD int lds_swz(int idx)
 #define PSDK_SWZ_MAX 4096
 #endif
     if constexpr (N >= 256 && N <= PSDK_SWZ_MAX)
-        return idx ^ ((idx >> 4) & 0x1F); // (256 ... 4096 since round 3: the unswizzled frame read at up to 9x the ideal LDS cycles)
+        return idx ^ ((idx >> 4) & 0x1F); // (512 ... 4096 since round 3: the unswizzled frame read at up to 9x the ideal LDS cycles; N <= 256: LdsFrame)
     else
         return idx;
 }
+
+// Where element e of a team's frame sits in LDS.  N > 256: the XOR swizzle above, frames of N elements.  N <= 256: a wavefront holds
+// 64 / TEAM teams (4 ... 16) whose frames are 1 ... 2 KiB apart, i.e. on the SAME banks -- conflict-free per team is 4- to 8-fold
+// conflicts per wavefront (N = 128 read 256 cycles for an ideal 32: `welch_kernel<128>` was LDS-bound, SQ_LDS_BANK_CONFLICT 0.62 of
+// its LDS cycles).  One element of padding per 2^K (e + (e >> K)) and frames of N + (N >> K) + PAD elements put every read
+// instruction of a wavefront at its ideal cycle count and every write at the ideal (N >= 128) or 1.5x of it (tests/host/fft_emul.cpp
+// counts them per WAVEFRONT now; K and PAD found by exhaustive search over that model).
+template <int N>
+struct LdsFrame {
+    static constexpr bool PADDED = N <= 256;
+    static constexpr int K = N <= 64 ? 2 : N == 128 ? 3 : 4;
+    static constexpr int PAD = N == 128 ? 8 : 0;
+    static constexpr int SIZE = PADDED ? N + (N >> K) + PAD : N; // elements of one team's frame
+    static PSDK_HD int at(int e)
+    {
+        if constexpr (PADDED)
+            return e + (e >> K);
+        else
+            return lds_swz<N>(e);
+    }
+};
 
 // Frequency bin held at natural position `pos` after all DIF passes:
 // pos = sum_p d_p * N/(R_0..R_p)  ->  k = sum_p d_p * (R_0..R_{p-1}).
@@ -315,7 +336,7 @@ PSDK_HD void pass_store(int t, const cf *v, cf *frame)
     for (int i = 0; i < PI::NB; ++i)
 #pragma unroll
         for (int q = 0; q < PI::R; ++q)
-            frame[lds_swz<N>(PI::elem(t, i, q))] = v[i * PI::R + q];
+            frame[LdsFrame<N>::at(PI::elem(t, i, q))] = v[i * PI::R + q];
 }
 
 // read the inputs of pass P from the team's LDS frame.  In the LAST pass the
@@ -330,7 +351,7 @@ PSDK_HD void pass_load(int t, cf *v, const cf *frame, int rot = 0)
 #pragma unroll
         for (int m = 0; m < PI::R; ++m) {
             const int mm = PI::LAST ? ((m + rot) % PI::R) : m;
-            v[i * PI::R + m] = frame[lds_swz<N>(PI::elem(t, i, mm))];
+            v[i * PI::R + m] = frame[LdsFrame<N>::at(PI::elem(t, i, mm))];
         }
 }
 

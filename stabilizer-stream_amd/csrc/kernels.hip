@@ -70,10 +70,26 @@ __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__
     }
 }
 
+// No packed-f32 VALU ops in these kernels: on CDNA4 a v_pk_* is two passes through the SIMD and costs register pairing (moves);
+// the backend forms them from the complex arithmetic anyway (welch_kernel<128>: 357 packed ops + 243 moves of 1117 VALU instructions).
+// The attribute turns the target feature off per kernel -- the forced-inline helpers follow the kernel they are inlined into.
+// Measured on the all-scalar build, same box, alternating: welch_kernel N = 16 ... 16384 +4 ... +48 % (128: 204 -> 301 GS/s, 256: 281 ->
+// 380, 8192: 152 -> 193, 16384: 108 -> 134; 512 ... 4096: +6 %), the chirp-z kernel +44 % at M = 256, +3.5 / +8 % at M = 8192 / 16384 but
+// -1.5 ... -9 % at M = 512 ... 4096, which therefore keep the packed form (launch_welch picks); the decimator and post kernels: no change.
+// (__syncthreads() called DIRECTLY from a kernel with the attribute below stayed a real call: the header's function has the default
+// target features.  Through this forced-inline wrapper it is inlined where it is written first.)
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PSDK_SCALAR_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define PSDK_SCALAR_F32 // (the host pass of hipcc knows no such feature)
+#endif
+
 // FR: the launch holds jobs whose stream is read in place from AdcDac frames (a runtime branch per load otherwise sat in
 // every launch: N = 128 lost 30 % to it)
 template <int N, bool FR = false>
-__global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBatch batch,
+__global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kernel(const WelchBatch batch,
                                                                   const float *__restrict__ win,
                                                                   const cf *__restrict__ tw)
 {
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
     using P0 = PassInfo<N, 0>;
     constexpr int E = Cfg::E, TEAM = Cfg::TEAM, TEAMS = Cfg::TEAMS, SPT = Cfg::SPT;
 
-    __shared__ cf frames[TEAMS * N];
+    __shared__ cf frames[TEAMS * LdsFrame<N>::SIZE];
     __shared__ float red[Cfg::WAVES * 2];
 
     // workgroup -> job; this workgroup walks the job's tiles lt = wb, wb + nblocks, ...
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
 
     const int team = threadIdx.x / TEAM;
     const int t = threadIdx.x % TEAM;
-    cf *frame = frames + team * N;
+    cf *frame = frames + team * LdsFrame<N>::SIZE;
     const int hop = batch.hop;
     const int detrend = batch.detrend;
 
@@ -114,14 +130,16 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
         const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
         const bool fr = job.fspan >= 0;
         const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
-        auto xa = [&](int j) {
+        // (always_inline on the lambdas: a lambda does not carry the kernel's target attribute, and a callee with other target features
+        // is not inlined unless it must be -- left alone they became 42 calls with scratch traffic inside the loop: N = 128 read 61 GS/s)
+        auto xa = [&](int j) __attribute__((always_inline)) {
             if constexpr (FR) {
                 if (fr)
                     return frame_sample(fsp, job.fch, (unsigned long long)(ofs_a + job.s_off + j));
             }
             return job.src[ofs_a + j];
         };
-        auto xb = [&](int j) { return xa(j + hop); };
+        auto xb = [&](int j) __attribute__((always_inline)) { return xa(j + hop); };
 
         float ra[E], rb[E];
 #pragma unroll
@@ -151,7 +169,7 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
             }
         } else if (detrend == 3) { // Mean :103-109 in two steps: o = f32 mean of the samples, m = mean of x - o
             // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
-            auto team_sum2 = [&](float &pa, float &pb) {
+            auto team_sum2 = [&](float &pa, float &pb) __attribute__((always_inline)) {
                 constexpr int W = TEAM < 64 ? TEAM : 64;
 #pragma unroll
                 for (int o = W / 2; o > 0; o >>= 1) {
@@ -166,14 +184,14 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
                         red[2 * w] = pa;
                         red[2 * w + 1] = pb;
                     }
-                    __syncthreads();
+                    block_sync();
                     pa = 0.0f;
                     pb = 0.0f;
                     for (int i = 0; i < WPT; ++i) {
                         pa += red[2 * (team * WPT + i)];
                         pb += red[2 * (team * WPT + i) + 1];
                     }
-                    __syncthreads();
+                    block_sync();
                 }
             };
             float pa = 0.0f, pb = 0.0f;
@@ -236,11 +254,11 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) void welch_kernel(const WelchBa
 
     // combine the teams and write the workgroup's partial in natural bin order
     float *fq = reinterpret_cast<float *>(frames);
-    __syncthreads();
+    block_sync();
 #pragma unroll
     for (int s = 0; s < E; ++s)
         fq[team * N + freq_of_slot<N>(t, s)] = q[s];
-    __syncthreads();
+    block_sync();
     float *out = job.partial + (size_t)wb * N;
     for (int k = threadIdx.x; k < N; k += Cfg::BLOCK) {
         float acc = 0.0f;
@@ -274,14 +292,14 @@ struct BlueCfg {
 };
 
 template <int M>
-__global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(const WelchBatch batch, int n, const float *__restrict__ win,
-                                                                          const cf *__restrict__ twm, const cf *__restrict__ chirp,
-                                                                          const cf *__restrict__ bhat)
+__device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, int n, const float *__restrict__ win,
+                                                     const cf *__restrict__ twm, const cf *__restrict__ chirp,
+                                                     const cf *__restrict__ bhat)
 {
     using Cfg = BlueCfg<M>;
     using P0 = PassInfo<M, 0>;
     constexpr int E = Cfg::E, TEAM = Cfg::TEAM, TEAMS = Cfg::TEAMS, SPT = Cfg::SPT;
-    __shared__ cf frames[TEAMS * M];
+    __shared__ cf frames[TEAMS * LdsFrame<M>::SIZE];
     __shared__ float red[Cfg::WAVES * 2];
 
     int ji = 0;
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
     const int wb = blockIdx.x - job.block_begin;
     const int team = threadIdx.x / TEAM;
     const int t = threadIdx.x % TEAM;
-    cf *frame = frames + team * M;
+    cf *frame = frames + team * LdsFrame<M>::SIZE;
     const int hop = batch.hop;
     const int detrend = batch.detrend;
     const float inv_n = 1.0f / (float)n;
@@ -310,8 +328,8 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
         const int la = seg_lo + 2 * p;
         const bool act_a = la < seg_hi, act_b = la + 1 < seg_hi;
         const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
-        auto xa = [&](int j) { return job.src[ofs_a + j]; };
-        auto xb = [&](int j) { return job.src[ofs_a + hop + j]; };
+        auto xa = [&](int j) __attribute__((always_inline)) { return job.src[ofs_a + j]; };
+        auto xb = [&](int j) __attribute__((always_inline)) { return job.src[ofs_a + hop + j]; };
 
         float ra[E], rb[E];
 #pragma unroll
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
                 sb = span_slope(ob, xb(n - 1), n);
             }
         } else if (detrend == 3) {
-            auto team_sum2 = [&](float &pa, float &pb) {
+            auto team_sum2 = [&](float &pa, float &pb) __attribute__((always_inline)) {
                 constexpr int W = TEAM < 64 ? TEAM : 64;
 #pragma unroll
                 for (int o = W / 2; o > 0; o >>= 1) {
@@ -425,14 +443,14 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
         for (int s = 0; s < E; ++s) { // conj(Y B), back in natural order for the second transform
             const int j = freq_of_slot<M>(t, s);
             const cf u = cmul(v[s], bhat[j]);
-            frame[lds_swz<M>(j)] = {u.re, -u.im};
+            frame[LdsFrame<M>::at(j)] = {u.re, -u.im};
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < P0::NB; ++i)
 #pragma unroll
             for (int m = 0; m < P0::R; ++m)
-                v[i * P0::R + m] = frame[lds_swz<M>(P0::elem(t, i, m))];
+                v[i * P0::R + m] = frame[LdsFrame<M>::at(P0::elem(t, i, m))];
         fft_passes<M, 0, true>(t, v, frame, twm); // M conj(convolution): slot s holds output index freq_of_slot<M>(t, s); only |.|^2 is used
 #pragma unroll
         for (int s = 0; s < E; ++s)
@@ -456,6 +474,24 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(cons
             acc += fq[g * M + k];
         out[k] = acc * scale;
     }
+}
+
+// the kernel in its two builds (PSDK_SCALAR_F32 above): packed f32 for M = 512 ... 4096, all-scalar elsewhere
+template <int M>
+__global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(const WelchBatch batch, int n, const float *__restrict__ win,
+                                                                          const cf *__restrict__ twm, const cf *__restrict__ chirp,
+                                                                          const cf *__restrict__ bhat)
+{
+    welch_bluestein_body<M>(batch, n, win, twm, chirp, bhat);
+}
+template <int M>
+__global__ __launch_bounds__(BlueCfg<M>::BLOCK) PSDK_SCALAR_F32 void welch_bluestein_kernel_scalar(const WelchBatch batch, int n,
+                                                                                              const float *__restrict__ win,
+                                                                                              const cf *__restrict__ twm,
+                                                                                              const cf *__restrict__ chirp,
+                                                                                              const cf *__restrict__ bhat)
+{
+    welch_bluestein_body<M>(batch, n, win, twm, chirp, bhat);
 }
 
 // ---------------------------------------------------------------------------
@@ -895,8 +931,12 @@ hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *
     switch (bluestein_size(n)) { // tw: W_M^j, chirp: exp(i pi j^2 / n), bhat: FFT_M of the wrapped chirp
 #define PSDK_CASE(MM)                                                                                          \
     case MM:                                                                                                   \
-        hipLaunchKernelGGL(welch_bluestein_kernel<MM>, dim3(b.nblocks), dim3(BlueCfg<MM>::BLOCK), 0, s, b, n, win, tw, \
-                           chirp, bhat);                                                                       \
+        if (MM >= 512 && MM <= 4096)                                                                           \
+            hipLaunchKernelGGL(welch_bluestein_kernel<MM>, dim3(b.nblocks), dim3(BlueCfg<MM>::BLOCK), 0, s, b, n, win, tw, \
+                               chirp, bhat);                                                                   \
+        else                                                                                                   \
+            hipLaunchKernelGGL(welch_bluestein_kernel_scalar<MM>, dim3(b.nblocks), dim3(BlueCfg<MM>::BLOCK), 0, s, b, n, win, tw, \
+                               chirp, bhat);                                                                   \
         return hipGetLastError();
         PSDK_CASE(32)
         PSDK_CASE(64)

@@ -48,19 +48,21 @@ static void run_pass(std::vector<std::vector<cf>> &regs, std::vector<cf> &frame,
             int rot = (rotate && PI::LAST) ? ((t >> 3) & (PI::R - 1)) : 0;
             pass_load<N, P>(t, regs[t].data(), frame.data(), rot);
         }
-        // conflicts of the read instructions: one instruction per (i, m)
+        // conflicts of the read instructions, one instruction per (i, m), over a WAVEFRONT: lane l belongs to team l / TEAM of the
+        // wave (frames LdsFrame<N>::SIZE apart) when a team is smaller than the wave, to wave l / 64 of the team otherwise
+        constexpr int LANES = TEAM < 64 ? 64 : TEAM;
         for (int i = 0; i < PI::NB; ++i)
             for (int m = 0; m < PI::R; ++m)
-                for (int w0 = 0; w0 < TEAM; w0 += 64)
+                for (int w0 = 0; w0 < LANES; w0 += 64)
                     for (int g = 0; g < 2; ++g) {
                         std::vector<int> s;
-                        for (int l = 0; l < 32 && w0 + g * 32 + l < TEAM; ++l) {
-                            int t = w0 + g * 32 + l;
+                        for (int l = 0; l < 32; ++l) {
+                            const int lane = w0 + g * 32 + l;
+                            const int j = TEAM < 64 ? lane / TEAM : 0, t = TEAM < 64 ? lane % TEAM : lane;
                             int rot = (rotate && PI::LAST) ? ((t >> 3) & (PI::R - 1)) : 0;
                             int mm = PI::LAST ? (m + rot) % PI::R : m;
-                            s.push_back(lds_swz<N>(PI::elem(t, i, mm)));
+                            s.push_back(j * LdsFrame<N>::SIZE + LdsFrame<N>::at(PI::elem(t, i, mm)));
                         }
-                        if (s.empty()) continue;
                         conf.rd += group_cycles(s, 32);
                         conf.rd_ideal += 1;
                     }
@@ -70,12 +72,16 @@ static void run_pass(std::vector<std::vector<cf>> &regs, std::vector<cf> &frame,
     if constexpr (!PI::LAST) {
         for (int t = 0; t < TEAM; ++t)
             pass_store<N, P>(t, regs[t].data(), frame.data());
+        constexpr int LANES = TEAM < 64 ? 64 : TEAM;
         for (int i = 0; i < PI::NB; ++i)
             for (int q = 0; q < PI::R; ++q)
-                for (int w0 = 0; w0 < TEAM; w0 += 16) {
+                for (int w0 = 0; w0 < LANES; w0 += 16) {
                     std::vector<int> s;
-                    for (int l = 0; l < 16 && w0 + l < TEAM; ++l)
-                        s.push_back(lds_swz<N>(PI::elem(w0 + l, i, q)));
+                    for (int l = 0; l < 16; ++l) {
+                        const int lane = w0 + l;
+                        const int j = TEAM < 64 ? lane / TEAM : 0, t = TEAM < 64 ? lane % TEAM : lane;
+                        s.push_back(j * LdsFrame<N>::SIZE + LdsFrame<N>::at(PI::elem(t, i, q)));
+                    }
                     conf.wr += group_cycles(s, 16);
                     conf.wr_ideal += 1;
                 }
@@ -88,7 +94,7 @@ static int check(bool rotate)
 {
     using Plan = FftPlan<N>;
     constexpr int E = Plan::E, TEAM = Plan::TEAM;
-    std::vector<cf> z(N), tw(N), frame(N);
+    std::vector<cf> z(N), tw(N), frame(LdsFrame<N>::SIZE);
     srand(1234 + N);
     for (int i = 0; i < N; ++i) {
         z[i].re = (float)rand() / RAND_MAX - 0.5f;
