@@ -29,9 +29,10 @@ def dominant(rows, counter=None):
     tot = {}
     for r in rows:
         k = r["Kernel_Name"]
-        if "fused_kernel" not in k and "fused3_kernel" not in k and "welch_kernel" not in k and "bigfft_" not in k:
-            continue
-        if ksub and ksub not in k:
+        if ksub:  # an explicit kernel-name substring picks among ALL kernels
+            if ksub not in k:
+                continue
+        elif "fused_kernel" not in k and "fused3_kernel" not in k and "welch_kernel" not in k and "bigfft_" not in k:
             continue
         tot[k] = tot.get(k, 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return max(tot, key=tot.get) if tot else None
