@@ -213,7 +213,13 @@ struct Dft {
 template <int N>
 struct FftPlan {
     static_assert(N >= 16 && (N & (N - 1)) == 0, "N must be a power of two >= 16");
-    static constexpr int E = N >= 128 ? 16 : 4; // (N = 128: two passes (16, 8) instead of four of radix 4: 176 -> 197 GS/s; at N = 64 the same read 5 % lower)
+#ifndef PSDK_E16_MIN
+#define PSDK_E16_MIN 64
+#endif
+    // sixteen elements a thread from N = 64 up: N = 128 two passes (16, 8) instead of four of radix 4 (176 -> 197 GS/s in round 3),
+    // N = 64 two passes (16, 4) instead of three (234 -> 295 GS/s once the kernel was all-scalar; with packed ops it had read 5 % lower);
+    // N = 32 / 16 with sixteen a thread are teams of 2 / 1 lanes whose loads no longer coalesce: 231 -> 157, 259 -> 178 GS/s
+    static constexpr int E = N >= PSDK_E16_MIN ? 16 : 4;
     static constexpr int TEAM = N / E;
 
     static constexpr int len(int p) // sub-transform length entering pass p
@@ -278,8 +284,9 @@ PSDK_HD int lds_swz(int idx)
 template <int N>
 struct LdsFrame {
     static constexpr bool PADDED = N <= 256;
-    static constexpr int K = N <= 64 ? 2 : N == 128 ? 3 : 4;
-    static constexpr int PAD = N == 128 ? 8 : 0;
+    static constexpr bool E16 = FftPlan<N>::E == 16;
+    static constexpr int K = (N == 32 && E16) ? 1 : N <= 64 ? 2 : N == 128 ? 3 : 4;
+    static constexpr int PAD = N == 128 ? 8 : (N == 64 && E16) ? 4 : (N == 32 && E16) ? 2 : 0;
     static constexpr int SIZE = PADDED ? N + (N >> K) + PAD : N; // elements of one team's frame
     static PSDK_HD int at(int e)
     {
