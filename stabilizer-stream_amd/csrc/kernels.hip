@@ -50,6 +50,21 @@ __device__ __forceinline__ float ewma_amp(const SegJob &job, int step)
 // 192 -> 176 at 2048, 2048 -> 1536 at 16384; the other sizes are at or near their ideal without it).  The first transform of the
 // chirp-z kernel needs the outputs themselves and must not rotate: it did at M = 1024 (sizes 256 < N <= 512 that are not
 // powers of two read wrong spectra until round 3's last day; tests/test_gpu_any_n.py now covers every transform length).
+// A team's frame is private to the team.  Teams of at most 64 lanes sit inside ONE wavefront, whose LDS operations execute in
+// order: the hand-off between the lanes of a team then needs no workgroup barrier, only the compiler kept from moving LDS
+// accesses across it (as in fused_common.h wave_sync).  Larger teams span wavefronts and keep __syncthreads().
+template <int TEAM>
+__device__ __forceinline__ void team_sync()
+{
+    if constexpr (TEAM <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int N, int P, bool POWER_ONLY>
 __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__restrict__ tw)
 {
@@ -63,9 +78,9 @@ __device__ __forceinline__ void fft_passes(int t, cf *v, cf *frame, const cf *__
     pass_compute<N, P>(t, v, tw);
     if constexpr (!PI::LAST) {
         if constexpr (P == 0)
-            __syncthreads(); // previous iteration's last-pass reads are done
+            team_sync<PI::TEAM>(); // previous iteration's last-pass reads are done
         pass_store<N, P>(t, v, frame);
-        __syncthreads();
+        team_sync<PI::TEAM>();
         fft_passes<N, P + 1, POWER_ONLY>(t, v, frame, tw);
     }
 }
@@ -438,14 +453,14 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
             }
 
         fft_passes<M, 0, false>(t, v, frame, twm); // Y = FFT_M(y): slot s holds bin freq_of_slot<M>(t, s) (the VALUES are used: no rotation)
-        __syncthreads();                    // everybody's last-pass reads of the frame are done
+        team_sync<TEAM>();                  // the team's last-pass reads of its frame are done
 #pragma unroll
         for (int s = 0; s < E; ++s) { // conj(Y B), back in natural order for the second transform
             const int j = freq_of_slot<M>(t, s);
             const cf u = cmul(v[s], bhat[j]);
             frame[LdsFrame<M>::at(j)] = {u.re, -u.im};
         }
-        __syncthreads();
+        team_sync<TEAM>();
 #pragma unroll
         for (int i = 0; i < P0::NB; ++i)
 #pragma unroll
