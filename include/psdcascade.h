@@ -248,7 +248,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                                       size_t n_frames, size_t *n_ok);
 
 /* psdc_process_frames for frames that already sit in device memory: any of the four formats, in runs.  The headers (8 of every
- * frame_size bytes) come to the host in one strided copy and are validated there; the payloads stay on the device -- Fls /
+ * frame_size bytes) are gathered into pinned memory by one small kernel on a side stream and validated on the host; the payloads stay on the device -- Fls /
  * ThermostatEem / Mpll runs are decoded straight from `d_frames` into the stage-0 streams, AdcDac runs take
  * psdc_process_adcdac_frames_device (whose lifetime, ordering and alignment rules apply to the whole call: d_frames valid and
  * unmodified until psdc_sync() / a read-out / a psdc_record_consumed event, its producer COMPLETED before the call). */

@@ -220,6 +220,10 @@ hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_fram
 hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, float *dst0, float *dst1,
                           float *dst2, float *dst3, hipStream_t s);
 
+// the 8 header bytes of each of n_frames device-resident frames into out_pinned (pinned host memory, 8 n_frames bytes, little-endian
+// as on the wire)
+hipError_t launch_header_gather(const uint8_t *frames, size_t frame_size, size_t n_frames, void *out_pinned, hipStream_t s);
+
 // device-resident frames: header checks of every frame (check != 0) and the Loss counters over the first n_loss, in ONE
 // launch; the four result words land in host_out (pinned host memory) when the stream has run the kernel: host_out[0] =
 // max ~(index << 2 | code) over the bad frames (0: none), [1] batches received, [2] sequence gaps, [3] first seq | next seq

@@ -1065,6 +1065,31 @@ hipError_t launch_adcdac(const uint8_t *frames, size_t frame_size, size_t n_fram
     return hipGetLastError();
 }
 
+// the 8 header bytes of every frame, gathered into pinned host memory (out[f] = {magic | id << 16 | batches << 24, seq}): the general
+// device ingest validates them on the host (psdc_process_frames_device); one 8-byte load per frame when the frames are 8-byte aligned
+__global__ __launch_bounds__(256) void header_gather_kernel(const uint8_t *__restrict__ frames, size_t frame_size, size_t n_frames, uint2 *out)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(frames) | frame_size) & 7u) == 0;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (size_t)gridDim.x * 256) {
+        const uint8_t *p = frames + f * frame_size;
+        uint2 h;
+        if (aligned)
+            h = *reinterpret_cast<const uint2 *>(p);
+        else
+            h = make_uint2((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24),
+                           (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24));
+        out[f] = h;
+    }
+}
+hipError_t launch_header_gather(const uint8_t *frames, size_t frame_size, size_t n_frames, void *out_pinned, hipStream_t s)
+{
+    if (n_frames == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (n_frames + 255) / 256);
+    hipLaunchKernelGGL(header_gather_kernel, dim3(blocks), dim3(256), 0, s, frames, frame_size, n_frames, static_cast<uint2 *>(out_pinned));
+    return hipGetLastError();
+}
+
 hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, float *dst0, float *dst1,
                           float *dst2, float *dst3, hipStream_t s)
 {

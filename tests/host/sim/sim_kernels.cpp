@@ -477,6 +477,16 @@ hipError_t launch_payload(int fmt, const uint8_t *frames, size_t frame_size, siz
     return hipSuccess;
 }
 
+// ---- header_gather_kernel: the 8 header bytes of every frame into pinned host memory ----------------------------------------
+hipError_t launch_header_gather(const uint8_t *frames, size_t frame_size, size_t n_frames, void *out_pinned, hipStream_t s)
+{
+    sim::enqueue(s, [=] {
+        for (size_t f = 0; f < n_frames; ++f)
+            memcpy(static_cast<uint8_t *>(out_pinned) + 8 * f, frames + f * frame_size, 8);
+    });
+    return hipSuccess;
+}
+
 // ---- adcdac_verdict_kernel: Header::parse + the AdcDac size checks + Loss::update, as the kernel defines its four words --
 hipError_t launch_adcdac_verdict(const uint8_t *frames, size_t frame_size, size_t n_frames, int batches, int payload_ok, int check,
                                  size_t n_loss, unsigned long long *acc, unsigned long long *host_out, hipStream_t s)

@@ -197,7 +197,7 @@ def test_source_feeds_a_frame_file_of_any_format(pkg, ora, gpu_required, tmp_pat
 
 def test_frames_resident_in_device_memory(pkg, ora, gpu_required):
     """psdc_process_frames_device: the same runs of AdcDac / Fls / Mpll frames (frame size 8 + 1344) from a device buffer -- the headers
-    go to the host in one strided copy, Fls / Mpll payloads are decoded from the caller's buffer, the AdcDac runs are read in place by
+    are gathered to the host by one small kernel, Fls / Mpll payloads are decoded from the caller's buffer, the AdcDac runs are read in place by
     the fused kernels (N = 1024) -- against the oracle, and against the host-memory call (same Loss, same pending samples bit for bit);
     then the de::Error of a bad frame in the middle of a device-resident Mpll run."""
     import torch
