@@ -2,7 +2,8 @@
 random calls, sequence gaps, now and then a bad frame (magic / unknown id / batch count) -- every trace must track the oracle's decode
 + cascade, the Loss counters the oracle's restatement, and the call must report the frames before the bad one.
 usage: python tools/payload_campaign.py [first] [count]
-Seeds 20000 ... 22999 of the final build: 2998 clean; the two others are the checker's thresholds meeting streams whose LEVEL steps between
+Even seeds feed host memory (psdc_process_frames), odd seeds the same calls from a device buffer (psdc_process_frames_device); seeds
+50000 ... 52499 of the last build: clean.  Seeds 20000 ... 22999 of an earlier form (host memory only): 2998 clean; the two others are the checker's thresholds meeting streams whose LEVEL steps between
 runs of different formats (trace 0 is a positive amplitude in one run and zero-mean noise in the next), not the decode: seed 20954 (15
 frames, a count-1 stage-1 spectrum with ONE bin beyond the pure tolerance: GPU error 4.9e-7 there against the f32 restatement's 4.1e-7 --
 a one-bin sample of the rms rule), seed 22144 (stage-3 pending samples 1.8e-6 off while the buffer's own largest sample, which the
@@ -72,9 +73,17 @@ for seed in range(first, first + count):
         g = pkg.PsdCascadeBank(n, 4)
         cuts = sorted(set([0, nf] + [int(v) for v in rng.integers(0, nf + 1, size=int(rng.integers(0, 5)))]))
         got_err, taken = None, 0
+        on_device = seed % 2 == 1  # odd seeds: the same calls from a device buffer (psdc_process_frames_device)
+        if on_device:
+            import torch
+            dev = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).cuda()
+            torch.cuda.synchronize()
         for a, b in zip(cuts, cuts[1:]):
             try:
-                taken += g.process_frames(b"".join(frames[a:b]), fs)
+                if on_device:
+                    taken += g.process_frames_device(dev.data_ptr() + a * fs, fs, b - a)
+                else:
+                    taken += g.process_frames(b"".join(frames[a:b]), fs)
             except pkg.FrameError as e:
                 got_err = e.code
                 break
@@ -95,6 +104,7 @@ for seed in range(first, first + count):
                 drop += (sq - nxt) & 0xFFFFFFFF
             nxt = (sq + nb) & 0xFFFFFFFF
         assert g.loss() == {"received": rec, "dropped": drop}, (g.loss(), rec, drop)
+        g.sync()
         for c in range(4):
             x = np.concatenate(want[c]) if want[c] else np.zeros(0, np.float32)
             if x.size == 0:
@@ -102,7 +112,7 @@ for seed in range(first, first + count):
             else:
                 T.check_against_oracle(pkg, ora, g, [x], n, channel=c, what=f"seed {seed} cascade {c}")
         g.close()
-        print(f"seed {seed} n={n} formats={subset} frame_size={fs} frames={nf} bad_at={bad_at} ok ({time.time() - t0:.0f}s)", flush=True)
+        print(f"seed {seed} n={n} formats={subset} frame_size={fs} frames={nf} bad_at={bad_at} {'device' if on_device else 'host'} ok ({time.time() - t0:.0f}s)", flush=True)
     except Exception:
         bad += 1
         print(f"seed {seed} n={n} formats={subset} frame_size={fs} frames={nf} bad_at={bad_at} FAILED", flush=True)
