@@ -549,13 +549,36 @@ __device__ __forceinline__ float hbf_point(const float *__restrict__ ev, const f
     return ev[j + ce] + acc;
 }
 
+// Four adjacent outputs j ... j + 3 (j a multiple of 4) of one half-band stage from ONE window of 2 M + 3 odd-phase samples held in
+// registers: 2 M + 7 LDS reads for four outputs where hbf_point reads 2 M + 1 for each (stage A: 37 against 124) -- the kernel spent
+// as long on its LDS reads as on its HBM loads (22 LDS words per input sample).  Every output's sum is formed in hbf_point's order.
+template <int M>
+__device__ __forceinline__ void hbf_points4(const float *__restrict__ ev, const float *__restrict__ od, const float *taps, int j, int ce,
+                                            int co, float (&y)[4])
+{
+    float w[2 * M + 3];
+#pragma unroll
+    for (int k = 0; k < 2 * M + 3; ++k)
+        w[k] = od[j + co + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            acc += (w[u + i] + w[u + 2 * M - 1 - i]) * taps[i];
+        y[u] = ev[j + u + ce] + acc;
+    }
+}
+
 template <bool FR>
 __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
 {
     using namespace dec;
-    __shared__ float xe[NX / 2], xo[NX / 2];
-    __shared__ float ae[NA_OUT / 2], ao[NA_OUT / 2];
-    __shared__ float be[NB_OUT / 2], bo[NB_OUT / 2];
+    // (+ 4: the last group of four outputs of a stage may reach up to three outputs -- and their window -- past the stage's length;
+    // those outputs are computed from whatever is there and never used)
+    __shared__ float xe[NX / 2 + 4], xo[NX / 2 + 4];
+    __shared__ __attribute__((aligned(8))) float ae[NA_OUT / 2 + 4], ao[NA_OUT / 2 + 4];
+    __shared__ __attribute__((aligned(8))) float be[NB_OUT / 2 + 4], bo[NB_OUT / 2 + 4];
 
     const int tile = blockIdx.x;
     int ji = 0;
@@ -588,27 +611,29 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
         xo[r] = o;
     }
     __syncthreads();
-    for (int j = tid; j < NA_OUT; j += 256) {
-        const float y = hbf_point<HBF_MA>(xe, xo, c_taps_a, j, A_CE, A_CO);
-        if (j & 1)
-            ao[j >> 1] = y;
-        else
-            ae[j >> 1] = y;
+    for (int j = 4 * tid; j < NA_OUT; j += 4 * 256) { // outputs j, j + 2 -> ae[j/2], ae[j/2 + 1]; j + 1, j + 3 -> ao[...]
+        float y[4];
+        hbf_points4<HBF_MA>(xe, xo, c_taps_a, j, A_CE, A_CO, y);
+        *reinterpret_cast<float2 *>(ae + (j >> 1)) = make_float2(y[0], y[2]);
+        *reinterpret_cast<float2 *>(ao + (j >> 1)) = make_float2(y[1], y[3]);
     }
     __syncthreads();
-    for (int j = tid; j < NB_OUT; j += 256) {
-        const float y = hbf_point<HBF_MB>(ae, ao, c_taps_b, j, B_CE, B_CO);
-        if (j & 1)
-            bo[j >> 1] = y;
-        else
-            be[j >> 1] = y;
+    for (int j = 4 * tid; j < NB_OUT; j += 4 * 256) {
+        float y[4];
+        hbf_points4<HBF_MB>(ae, ao, c_taps_b, j, B_CE, B_CO, y);
+        *reinterpret_cast<float2 *>(be + (j >> 1)) = make_float2(y[0], y[2]);
+        *reinterpret_cast<float2 *>(bo + (j >> 1)) = make_float2(y[1], y[3]);
     }
     __syncthreads();
-    if (tid < nvalid) {
-        const float y = hbf_point<HBF_MC>(be, bo, c_taps_c, tid, C_CE, C_CO);
-        const long long o = mt0 + tid - batch.drain; // drop the first `drain` outputs ever
-        if (o >= 0)
-            job.dst[o - job.dst_base] = y;
+    if (4 * tid < nvalid) { // (the first wavefront: 64 lanes x 4 outputs)
+        float y[4];
+        hbf_points4<HBF_MC>(be, bo, c_taps_c, 4 * tid, C_CE, C_CO, y);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long o = mt0 + 4 * tid + u - batch.drain; // drop the first `drain` outputs ever
+            if (4 * tid + u < nvalid && o >= 0)
+                job.dst[o - job.dst_base] = y[u];
+        }
     }
 }
 
