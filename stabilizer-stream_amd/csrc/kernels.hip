@@ -593,22 +593,43 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
     const int tid = threadIdx.x;
 
     // stage input -> even/odd polyphase arrays (zero history before the stream start)
-    for (int r = tid; r < NX / 2; r += 256) {
+    // (all of a thread's loads first, then its LDS stores: five sample pairs in flight a thread -- the kernel waits on memory, SQ 0.65 of
+    // its wave time; one 8-byte load a pair where the block's first sample is 8-byte aligned)
+    constexpr int XIT = (NX / 2 + 255) / 256;
+    float xev[XIT], xov[XIT];
+    const bool al8 = !(FR && job.fspan >= 0) && (reinterpret_cast<uintptr_t>(job.src + (x0 - job.src_base)) & 7u) == 0;
+#pragma unroll
+    for (int u = 0; u < XIT; ++u) {
+        const int r = tid + 256 * u;
         const long long i0 = x0 + 2 * r;
         float e = 0.0f, o = 0.0f;
-        if (i0 >= 0 && i0 + 1 < x_end) {
+        if (r < NX / 2 && i0 >= 0 && i0 + 1 < x_end) {
             if (FR && job.fspan >= 0) { // AdcDac frames read in place
                 const unsigned long long si = (unsigned long long)(i0 - job.src_base + job.s_off);
                 e = frame_sample(batch.fspans[job.fspan], job.fch, si);
                 o = frame_sample(batch.fspans[job.fspan], job.fch, si + 1);
             } else {
                 const float *p = job.src + (i0 - job.src_base);
-                e = p[0];
-                o = p[1];
+                if (al8) {
+                    const float2 v = *reinterpret_cast<const float2 *>(p);
+                    e = v.x;
+                    o = v.y;
+                } else {
+                    e = p[0];
+                    o = p[1];
+                }
             }
         }
-        xe[r] = e;
-        xo[r] = o;
+        xev[u] = e;
+        xov[u] = o;
+    }
+#pragma unroll
+    for (int u = 0; u < XIT; ++u) {
+        const int r = tid + 256 * u;
+        if (r < NX / 2) {
+            xe[r] = xev[u];
+            xo[r] = xov[u];
+        }
     }
     __syncthreads();
     for (int j = 4 * tid; j < NA_OUT; j += 4 * 256) { // outputs j, j + 2 -> ae[j/2], ae[j/2 + 1]; j + 1, j + 3 -> ao[...]
