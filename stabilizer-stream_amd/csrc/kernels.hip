@@ -147,14 +147,20 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kern
         const FrameSpan &fsp = batch.fspans[fr ? job.fspan : 0];
         // (always_inline on the lambdas: a lambda does not carry the kernel's target attribute, and a callee with other target features
         // is not inlined unless it must be -- left alone they became 42 calls with scratch traffic inside the loop: N = 128 read 61 GS/s)
-        auto xa = [&](int j) __attribute__((always_inline)) {
+        // Lanes without a segment (the odd last one of a tile) load the job's FIRST segment instead and drop the values: every load of
+        // the loop is then unconditional -- as `act ? x[..] : 0` each of the 32 loads of a pair sat in a basic block of its own behind an
+        // exec-mask branch.
+        const long long ofs_safe = job.seg0 * (long long)hop - job.src_base;
+        const long long ofs_la = act_a ? ofs_a : ofs_safe, ofs_lb = act_b ? ofs_a + hop : ofs_safe;
+        auto xat = [&](long long ofs, int j) __attribute__((always_inline)) {
             if constexpr (FR) {
                 if (fr)
-                    return frame_sample(fsp, job.fch, (unsigned long long)(ofs_a + job.s_off + j));
+                    return frame_sample(fsp, job.fch, (unsigned long long)(ofs + job.s_off + j));
             }
-            return job.src[ofs_a + j];
+            return job.src[ofs + j];
         };
-        auto xb = [&](int j) __attribute__((always_inline)) { return xa(j + hop); };
+        auto xa = [&](int j) __attribute__((always_inline)) { return xat(ofs_la, j); };
+        auto xb = [&](int j) __attribute__((always_inline)) { return xat(ofs_lb, j); };
 
         float ra[E], rb[E];
 #pragma unroll
@@ -162,8 +168,9 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kern
 #pragma unroll
             for (int m = 0; m < P0::R; ++m) {
                 const int nidx = P0::elem(t, i, m);
-                ra[i * P0::R + m] = act_a ? xa(nidx) : 0.0f;
-                rb[i * P0::R + m] = act_b ? xb(nidx) : 0.0f;
+                const float va = xa(nidx), vb = xb(nidx);
+                ra[i * P0::R + m] = act_a ? va : 0.0f;
+                rb[i * P0::R + m] = act_b ? vb : 0.0f;
             }
 
         // Detrend (src/psd.rs:75-113) as (x - o) - (m + n s): o is a sample of the segment, so the
@@ -171,16 +178,18 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kern
         float oa = 0.0f, ob = 0.0f, ma = 0.0f, mb = 0.0f;
         slope2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
         if (detrend == 1) { // Midpoint :87-93
-            oa = act_a ? xa(N / 2) : 0.0f;
-            ob = act_b ? xb(N / 2) : 0.0f;
+            const float va = xa(N / 2), vb = xb(N / 2);
+            oa = act_a ? va : 0.0f;
+            ob = act_b ? vb : 0.0f;
         } else if (detrend == 2) { // Span :94-102 (ramp evaluated as o0 + n*slope)
+            const float a0 = xa(0), a1 = xa(N - 1), b0 = xb(0), b1 = xb(N - 1);
             if (act_a) {
-                oa = xa(0);
-                sa = span_slope(oa, xa(N - 1), N);
+                oa = a0;
+                sa = span_slope(oa, a1, N);
             }
             if (act_b) {
-                ob = xb(0);
-                sb = span_slope(ob, xb(N - 1), N);
+                ob = b0;
+                sb = span_slope(ob, b1, N);
             }
         } else if (detrend == 3) { // Mean :103-109 in two steps: o = f32 mean of the samples, m = mean of x - o
             // (see fused.hip: neither a rounded offset nor a sample pivot leaves bins 0 and 1 alone)
@@ -306,7 +315,11 @@ struct BlueCfg {
     static constexpr int WAVES = BLOCK / 64;
 };
 
-template <int M>
+// UNCOND: every load of the pair loop unconditional, as in welch_kernel (lanes without a segment read the job's first one, slots of
+// the zero padding read index n - 1, the values are dropped).  It removes a branch per load and costs registers: +8 ... +21 % at
+// M = 512 ... 4096 (N = 240: 69 -> 79 GS/s, 2000: 63 -> 76), but M <= 256 goes from 240 to 360 registers (one wavefront a SIMD instead
+// of two: N = 112 104 -> 82) and M = 16384 spills 300 more bytes (N = 8000 26 -> 21): those keep the conditional loads.
+template <int M, bool UNCOND>
 __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, int n, const float *__restrict__ win,
                                                      const cf *__restrict__ twm, const cf *__restrict__ chirp,
                                                      const cf *__restrict__ bhat)
@@ -343,8 +356,12 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
         const int la = seg_lo + 2 * p;
         const bool act_a = la < seg_hi, act_b = la + 1 < seg_hi;
         const long long ofs_a = (job.seg0 + la) * (long long)hop - job.src_base;
-        auto xa = [&](int j) __attribute__((always_inline)) { return job.src[ofs_a + j]; };
-        auto xb = [&](int j) __attribute__((always_inline)) { return job.src[ofs_a + hop + j]; };
+        // unconditional loads, as in welch_kernel: lanes without a segment read the job's first one, slots of the zero padding (index >= n)
+        // read sample n - 1, and the values are dropped
+        const long long ofs_safe = job.seg0 * (long long)hop - job.src_base;
+        const long long ofs_la = (UNCOND && !act_a) ? ofs_safe : ofs_a, ofs_lb = (UNCOND && !act_b) ? ofs_safe - hop : ofs_a;
+        auto xa = [&](int j) __attribute__((always_inline)) { return job.src[ofs_la + j]; };
+        auto xb = [&](int j) __attribute__((always_inline)) { return job.src[ofs_lb + hop + j]; };
 
         float ra[E], rb[E];
 #pragma unroll
@@ -352,8 +369,15 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
 #pragma unroll
             for (int m = 0; m < P0::R; ++m) {
                 const int nidx = P0::elem(t, i, m);
-                ra[i * P0::R + m] = (act_a && nidx < n) ? xa(nidx) : 0.0f;
-                rb[i * P0::R + m] = (act_b && nidx < n) ? xb(nidx) : 0.0f;
+                if constexpr (UNCOND) {
+                    const int jc = nidx < n ? nidx : n - 1;
+                    const float va = xa(jc), vb = xb(jc);
+                    ra[i * P0::R + m] = (act_a && nidx < n) ? va : 0.0f;
+                    rb[i * P0::R + m] = (act_b && nidx < n) ? vb : 0.0f;
+                } else {
+                    ra[i * P0::R + m] = (act_a && nidx < n) ? xa(nidx) : 0.0f;
+                    rb[i * P0::R + m] = (act_b && nidx < n) ? xb(nidx) : 0.0f;
+                }
             }
 
         // detrend parameters as in welch_kernel (src/psd.rs:75-113)
@@ -433,7 +457,24 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
                 const int s = i * P0::R + m;
                 const int nidx = P0::elem(t, i, m);
                 cf z = {0.0f, 0.0f};
-                if (nidx < n) {
+                if constexpr (UNCOND) { // (table reads unconditional too; padded slots are zeroed afterwards)
+                    const int jc = nidx < n ? nidx : n - 1;
+                    const float w = win[jc];
+                    const cf c = chirp[jc]; // y = z conj(c)
+                    float a = ra[s], b = rb[s];
+                    if (detrend != 0) {
+                        a = fmaf(-(float)nidx, sa.lo, fmaf(-(float)nidx, sa.hi, a - oa)) - ma;
+                        b = fmaf(-(float)nidx, sb.lo, fmaf(-(float)nidx, sb.hi, b - ob)) - mb;
+                    }
+                    a *= w;
+                    b *= w;
+                    if (job.ewma) {
+                        a *= ampa;
+                        b *= ampb;
+                    }
+                    if (nidx < n)
+                        z = {a * c.re + b * c.im, b * c.re - a * c.im};
+                } else if (nidx < n) {
                     const float w = win[nidx];
                     float a = ra[s], b = rb[s];
                     if (detrend != 0) {
@@ -491,13 +532,14 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
     }
 }
 
-// the kernel in its two builds (PSDK_SCALAR_F32 above): packed f32 for M = 512 ... 4096, all-scalar elsewhere
+// the kernel in its two builds: packed f32 (PSDK_SCALAR_F32 above) and unconditional loads for M = 512 ... 4096, all-scalar with
+// conditional loads elsewhere
 template <int M>
 __global__ __launch_bounds__(BlueCfg<M>::BLOCK) void welch_bluestein_kernel(const WelchBatch batch, int n, const float *__restrict__ win,
                                                                           const cf *__restrict__ twm, const cf *__restrict__ chirp,
                                                                           const cf *__restrict__ bhat)
 {
-    welch_bluestein_body<M>(batch, n, win, twm, chirp, bhat);
+    welch_bluestein_body<M, true>(batch, n, win, twm, chirp, bhat);
 }
 template <int M>
 __global__ __launch_bounds__(BlueCfg<M>::BLOCK) PSDK_SCALAR_F32 void welch_bluestein_kernel_scalar(const WelchBatch batch, int n,
@@ -506,7 +548,7 @@ __global__ __launch_bounds__(BlueCfg<M>::BLOCK) PSDK_SCALAR_F32 void welch_blues
                                                                                               const cf *__restrict__ chirp,
                                                                                               const cf *__restrict__ bhat)
 {
-    welch_bluestein_body<M>(batch, n, win, twm, chirp, bhat);
+    welch_bluestein_body<M, false>(batch, n, win, twm, chirp, bhat);
 }
 
 // ---------------------------------------------------------------------------
