@@ -104,6 +104,8 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // FR: the launch holds jobs whose stream is read in place from AdcDac frames (a runtime branch per load otherwise sat in
 // every launch: N = 128 lost 30 % to it)
 template <int N, bool FR = false>
+// (the kernel holds ~200 registers at N = 128: two wavefronts a SIMD.  Asking for three or four -- 168 / 128 registers, 148 / 288 bytes
+// of scratch -- measured 403 -> 317 / 289 GS/s.)
 __global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kernel(const WelchBatch batch,
                                                                   const float *__restrict__ win,
                                                                   const cf *__restrict__ tw)
