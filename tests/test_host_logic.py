@@ -365,6 +365,31 @@ def test_kernels_pass_the_machine_verifier():
     assert "every kernel TU clean" in r.stdout
 
 
+def test_generic_kernels_contain_no_calls_and_no_packed_ops_where_scalar(tmp_path):
+    """csrc/kernels.hip builds welch_kernel (every size) and the chirp-z kernel (M <= 256, M >= 8192) all-scalar through a per-kernel
+    target attribute.  A lambda or `__syncthreads()` called directly in such a kernel does not carry the attribute and is then NOT
+    inlined: the first form of this change had 42 real calls with scratch traffic inside the pair loop (N = 128: 61 GS/s instead of
+    300).  Compiled to gfx950 assembly here (no GPU needed): no `s_swappc` anywhere in the TU, no `v_pk_*` f32 arithmetic in the
+    kernels that are meant to be scalar, and packed ops present in the chirp-z kernels that keep them."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "stabilizer-stream_amd", "csrc")
+    out = tmp_path / "kernels.s"
+    r = subprocess.run([hipcc, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                        os.path.join(csrc, "kernels.hip"), "-o", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert "s_swappc" not in asm and "s_call" not in asm
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN4psdk\w+):.*?\n(.*?)s_endpgm", asm, re.M | re.S)}
+    pk = lambda name: len(re.findall(r"v_pk_(add|mul|fma)_f32", bodies[name]))
+    scalar = [k for k in bodies if "welch_kernelILi" in k or "welch_bluestein_kernel_scalar" in k]
+    packed = [k for k in bodies if "welch_bluestein_kernelILi" in k]
+    assert len(scalar) >= 22 + 10 and len(packed) == 10, (len(scalar), len(packed))
+    for k in scalar:
+        assert pk(k) == 0, (k, pk(k))
+    assert all(pk(k) > 50 for k in packed if any(f"ILi{m}E" in k for m in (512, 1024, 2048, 4096)))
+
+
 def test_bench_traffic_record_is_of_the_benched_window():
     """bench.py's `roofline.traffic` is taken from the committed PMC passes of the SAME shape (profiles/*_traffic.json): the record of
     the rectangular-window kernel (same kernel family, size, samples) must not stand in for the headline's, nor the other way round."""
