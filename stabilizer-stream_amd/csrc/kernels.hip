@@ -647,22 +647,30 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
         const int r = tid + 256 * u;
         const long long i0 = x0 + 2 * r;
         float e = 0.0f, o = 0.0f;
-        if (r < NX / 2 && i0 >= 0 && i0 + 1 < x_end) {
-            if (FR && job.fspan >= 0) { // AdcDac frames read in place
+        const bool want = r < NX / 2 && i0 >= 0 && i0 + 1 < x_end;
+        if (FR && job.fspan >= 0) { // AdcDac frames read in place
+            if (want) {
                 const unsigned long long si = (unsigned long long)(i0 - job.src_base + job.s_off);
                 e = frame_sample(batch.fspans[job.fspan], job.fch, si);
                 o = frame_sample(batch.fspans[job.fspan], job.fch, si + 1);
-            } else {
-                const float *p = job.src + (i0 - job.src_base);
-                if (al8) {
-                    const float2 v = *reinterpret_cast<const float2 *>(p);
-                    e = v.x;
-                    o = v.y;
-                } else {
-                    e = p[0];
-                    o = p[1];
-                }
             }
+        } else {
+            // unconditional (as in welch_kernel): the index clamped into [0, x_end - 2] -- always inside the source: a negative index is
+            // the stream's start, where the source begins at sample 0 -- and the value dropped; (x0 and x_end are even: the clamp keeps
+            // the pair's parity and the 8-byte alignment)
+            const long long ic = i0 < 0 ? 0 : (i0 + 1 < x_end ? i0 : x_end - 2);
+            const float *p = job.src + (ic - job.src_base);
+            float ve, vo;
+            if (al8) {
+                const float2 v = *reinterpret_cast<const float2 *>(p);
+                ve = v.x;
+                vo = v.y;
+            } else {
+                ve = p[0];
+                vo = p[1];
+            }
+            e = want ? ve : 0.0f;
+            o = want ? vo : 0.0f;
         }
         xev[u] = e;
         xov[u] = o;
