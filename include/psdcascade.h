@@ -129,7 +129,7 @@ typedef struct psdc_profile {
  * tables with that overlap; they read the table and assume only the hop -- or 0: Window::rectangular() and caller-built
  * tables without overlap, where two disjoint segments share one transform (faster than the Hann path: half the FFT work).
  * Caller-built windows of another overlap, n < 256 and sizes that are not powers of two take the generic
- * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about a third of the rate;
+ * two-pass kernels (welch + hbf_dec8: same results, the stream is read twice, about half the rate;
  * sizes that are not powers of two evaluate the DFT in chirp-z form on a power-of-two transform of at
  * least twice the length: two such transforms per segment pair); the powers of two 32768 ... 131072 a four-step FFT with
  * one intermediate frame in device memory (100 ... 120 GS/s, +256 MiB per handle). */
@@ -143,7 +143,7 @@ psdc_handle *psdc_create(uint32_t n, int window_kind, uint32_t n_channels, int d
  * A table that compares equal, bit for bit and in its three constants, to Window::hann() or
  * Window::rectangular() is recognised as such; any table with overlap == n / 2 (Hann, a caller's Hamming,
  * Blackman, ...) runs the single-pass fused kernels, any other overlap the generic two-pass kernels (same
- * results, about a third of the rate). */
+ * results, about half the rate). */
 psdc_handle *psdc_create_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap,
                                 uint32_t n_channels, int device);
 
