@@ -248,3 +248,34 @@ def test_signal(pkg, length, seed, tone=0.0, dc=0.0, f0=0.01234):
 
 
 test_signal.__test__ = False
+
+
+def stage_stream_scale(ora, x, k, drain=35):
+    """max |sample| of the stage-k stream of input stream x (f64 restatement): stage k+1's stream is the /8 half-band
+    cascade of stage k's from a zero state minus the one-time drain (src/psd.rs:246-260).  The yardstick of the
+    pending-sample check: a pending buffer can hold a handful of samples near a zero crossing, so ITS maximum says
+    nothing about the scale the decimator's f32 rounding lives on."""
+    y = np.asarray(x, dtype=np.float64)
+    for _ in range(k):
+        y = ora.hbf_dec8(y, "f64")[drain:]
+    return float(np.max(np.abs(y))) if y.size else 0.0
+
+
+def assert_pending_close(gb, rb, k, stream_scale, what=""):
+    """Pending samples (PsdStage::buf, src/psd.rs:285-287) of stage k against the f64 oracle's.  Stage 0 holds the caller's own
+    f32 samples: exact.  A stage >= 1 holds decimator outputs (src/psd.rs:246-253): f32 FIR sums whose rounding is relative to the
+    STREAM's scale and grows with the depth (each stage filters the rounded stream of the one before): 2e-6 sqrt(8^min(k,3)) + 1e-6
+    of the stream's maximum -- the rule check_against_oracle has used since round 2, now anchored on the stream instead of on the
+    few samples that happen to be pending (round 4, stress seed 12091: DESIGN.md section 2)."""
+    gb, rb = np.asarray(gb, dtype=np.float64), np.asarray(rb, dtype=np.float64)
+    assert gb.shape == rb.shape, f"{what}: stage {k} pending {gb.shape} vs {rb.shape}"
+    if not rb.size:
+        return
+    if k == 0:
+        assert np.array_equal(gb, rb), f"{what}: stage 0 pending samples are the input's own and must be identical"
+        return
+    scale = max(1e-3, stream_scale)
+    tol = (2e-6 * (8 ** min(k, 3)) ** 0.5 + 1e-6) * scale
+    err = float(np.max(np.abs(gb - rb)))
+    assert err <= tol, (f"{what}: stage {k} pending samples: {rb.size} pending, max|pending| {float(np.max(np.abs(rb))):.6g}, stream scale "
+                        f"{stream_scale:.6g}, worst |gpu - ref| {err:.3g} = {err / scale:.3g} of the stream scale (tolerance {tol / scale:.3g})")
