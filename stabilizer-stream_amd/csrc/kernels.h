@@ -1,4 +1,4 @@
-// kernels.h -- launch interface between the host runtime (psdcascade.cpp) and
+// kernels.h -- launch interface between the host runtime (runtime.cpp, planner.cpp, frames_ingest.cpp, readout.cpp) and
 // the gfx950 kernels (kernels.hip).  Job descriptors travel by value in the
 // kernel argument segment (no descriptor copies, graph-capturable).
 #pragma once

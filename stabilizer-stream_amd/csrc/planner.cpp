@@ -1,0 +1,736 @@
+// planner.cpp -- one round of the cascade pipeline (PsdCascade::process, src/psd.rs:456-468, for every channel at once): the
+// segments and decimator outputs each (channel, stage) owes are turned into kernel jobs and launched.
+#include "host_runtime.h"
+
+#include <cmath>
+#include <complex>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include <algorithm>
+
+using namespace psdrt;
+
+namespace {
+
+struct Span { // one contiguous source of a (channel, stage) batch
+    const float *src;
+    uint64_t src_base;
+    uint64_t seg_a, seg_b; // segments [seg_a, seg_b)
+    uint64_t m_a, m_b;     // decimator outputs [m_a, m_b)
+    bool fixed = false;    // src is not the start of the stage's stream buffer (caller memory or a
+                           // seam region inside the buffer): leave it alone when buffers are re-based
+    int fpool = -1;        // >= 0: the source is trace fch of frame span fs_pool[fpool] read in place (src == nullptr)
+    int fch = 0;
+};
+
+struct Work {
+    uint32_t c, k;
+    uint64_t j_old, j_new, p_old, p_new;
+    EwmaPlan ew;
+    Span spans[2 * MAX_COALESCE];
+    int nspans = 0;
+};
+
+} // namespace
+
+namespace psdrt {
+
+// One round of the cascade pipeline: every (channel, stage) that has complete
+// segments in its stream buffer is issued, all stages in the SAME launches.
+// The decimator output of this round becomes visible to the next stage in the
+// next round (stage k+1 lags one round behind stage k), so a steady-state round
+// costs two launches whatever the depth: a post launch (the seam copy of this round with the
+// deferred epilogue of the last one) and the fused launch (plus the generic welch / decimator
+// kernels when something does not fit a pair).
+// The fused single-pass kernels read the window from its table and assume nothing about it but a hop of N/2: Window::hann()
+// and every caller-built Window<N> with overlap N/2 (Hamming, Blackman, ... -- src/psd.rs:12-20 has pub fields) run on them;
+// overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table) runs the same kernels in their SINGLE form -- one
+// segment per "pair", transformed with a zero imaginary part; the decimator consumes the stream exactly as before (round 4:
+// rectangular windows ran the generic two-pass kernels at a third of the rate).  Other overlaps take the generic kernels.
+// 0: no fused kernel for this window, 1: half-overlapped pairs, 2: single segments.
+int fused_window(const psdc_handle *h)
+{
+    if (h->window_kind == PSDC_WINDOW_HANN || (h->window_kind == PSDC_WINDOW_CUSTOM && 2 * (uint64_t)h->geo.overlap == h->n))
+        return 1;
+    static const bool no_single = getenv("PSDC_NO_SINGLE") != nullptr; // (A/B aid: rectangular windows on the generic kernels)
+    if (h->geo.overlap == 0 && !no_single)
+        return 2;
+    return 0;
+}
+
+// `all`: issue odd segments of decimated stages too (read-outs); the ingest path
+// leaves them for their partner.  *did_work tells whether anything was issued;
+// read-outs call rounds until idle.
+int advance_round(psdc_handle *h, bool *did_work, bool all)
+{
+    const Geometry &g = h->geo;
+    const int spt = welch_segments_per_tile((int)h->n);
+    const int fmode = fused_supported((int)h->n) ? fused_window(h) : 0;
+    const bool fast_ok = fmode != 0, single = fmode == 2;
+    // overlap 0 at the team-kernel sizes: two disjoint segments per transform (FusedBatch::single == 2) -- jobs and runs then hold
+    // an even number of single-segment "pairs".  $PSDC_NO_DOUBLE: one segment per transform everywhere (A/B aid)
+    static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
+    const bool dbl = single && !no_double && fused_double_supported((int)h->n);
+    const unsigned fstep = single ? 1 : 2;   // segments per fused "pair"
+    // a fused run starting at segment j decimates from sample j hop + N/2 on (half-overlapped pairs: the pair's new samples) -- or,
+    // overlap 0, from j N on: a single-segment step transforms exactly the samples it decimates, and its source pointer sits half
+    // a segment in front of the segment (run_src0)
+    const uint64_t half = (uint64_t)h->n / 2;
+    auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + (single ? 0 : half); };
+    auto run_src0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop - (single ? half : 0); }; // (seg >= 1 in single mode)
+    // fused runs rebuild their decimator state from the 288 samples before their first new
+    // sample (which sits N/2 after the run's first segment start): samples needed in front of it
+    const uint64_t need_pre = HBF_HALO > half ? HBF_HALO - half : 0;
+    // the seam must complete every segment that starts in the carried tail; on the fast path it
+    // is long enough for the tail side to end on a whole segment pair with need_pre samples of
+    // the new span in front of the in-place side
+    const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * half : 0);
+    *did_work = false;
+    {
+        int rc = wait_uploads(h);
+        if (rc)
+            return rc;
+    }
+
+    // zero-copy spans: copy the seam (the part that completes segments begun in
+    // the carried tail) behind the tail; the bulk is read in place.  One copy
+    // launch for all channels.  A channel may hold several spans (PSDC_OPT_COALESCE): each
+    // further span gets a seam REGION of its own in the stream buffer, behind the contiguous
+    // part -- the tail the span before it would have carried (read from that span's end) followed
+    // by the head of the span -- so that the segments straddling two spans see contiguous memory.
+    struct Region { // seam region of span i >= 1 of a channel
+        size_t off;      // floats from the start of the stream buffer
+        uint64_t base;   // absolute index of its first sample (the keep_from point after span i-1)
+    };
+    std::vector<std::vector<Region>> regions(h->n_channels);
+    {
+        std::vector<TailJob> seams;
+        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+            Channel &c = h->ch[ci];
+            if (!c.has_span())
+                continue;
+            StageState &s0 = c.st[0];
+            const size_t ns = c.spans.size();
+            // contiguous part: the carried tail + the seam of the first span
+            const uint64_t cp0 = std::min<uint64_t>(seam, c.spans[0].len);
+            size_t need = (size_t)(c.spans[0].first + cp0 - s0.buf.base);
+            regions[ci].resize(ns);
+            for (size_t i = 1; i < ns; ++i) {
+                StageState t; // the stage as it stands once span i-1 is consumed
+                t.segs = segments_for(g, c.spans[i].first);
+                t.dec = decimated_prefix(g, t.segs);
+                const uint64_t kf = keep_from(g, t);
+                if (kf < c.spans[i - 1].first)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: coalesced span shorter than the carried tail");
+                regions[ci][i] = {need, kf};
+                need += (size_t)(c.spans[i].first - kf) + (size_t)std::min<uint64_t>(seam, c.spans[i].len);
+            }
+            int rc = ensure_room(h, s0, s0.buf.base + need);
+            if (rc)
+                return rc;
+            float *buf = s0.buf.p[s0.buf.cur];
+            seams.push_back(span_copy(h, c.spans[0], c.spans[0].first, buf + (c.spans[0].first - s0.buf.base), (size_t)cp0));
+            s0.buf.end = c.spans[0].first + cp0;
+            for (size_t i = 1; i < ns; ++i) {
+                const Region &r = regions[ci][i];
+                const DeviceSpan &pv = c.spans[i - 1], &sp = c.spans[i];
+                const size_t back = (size_t)(sp.first - r.base);
+                seams.push_back(span_copy(h, pv, r.base, buf + r.off, back));
+                seams.push_back(span_copy(h, sp, sp.first, buf + r.off + back, (size_t)std::min<uint64_t>(seam, sp.len)));
+            }
+        }
+        int rc = launch_deferred(h, seams); // with the last round's epilogue
+        if (rc)
+            return rc;
+        h->fs_pool.clear(); // every job that named a pooled span has been launched; this round's jobs pool theirs afresh
+        HIPCHK(h, hipEventRecord(h->ev_post, h->stream)); // see order_upload
+        h->post_marked = true;
+    }
+
+    // collect the work of this round from the totals as they stand now
+    std::vector<Work> works;
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        Channel &c = h->ch[ci];
+        for (uint32_t k = 0; k < c.st.size(); ++k) {
+            StageState &s = c.st[k];
+            if (s.sink)
+                continue; // handed to the caller as it is (psdc_stage_process)
+            uint64_t j_new = segments_for(g, s.total);
+            // ingest path (all == false): a decimated stage issues whole segment pairs only, the odd
+            // segment waits for its partner -- it would cost a launch of the generic kernels every
+            // other round; read-outs (all == true) issue everything
+            if (!all && fmode == 1 && k >= 1 && ((j_new - s.segs) & 1))
+                j_new -= 1;
+            // ... and a decimated stage waits until it has a worthwhile batch: every job of a launch occupies at
+            // least one resident workgroup for the whole launch, and the deep stages of many channels (a handful
+            // of pairs per round each) otherwise hold ~10 % of the GPU's workgroup slots nearly idle (8 channels:
+            // 578 -> 6xx GS/s).  The pending samples simply stay in the stage's stream buffer (<= 1 MiB).
+            if (!all && fast_ok && k >= 1 && j_new - s.segs < 2 * (uint64_t)h->min_pairs)
+                j_new = s.segs;
+            if (j_new == s.segs)
+                continue;
+            Work w;
+            w.c = ci;
+            w.k = k;
+            w.j_old = s.segs;
+            w.j_new = j_new;
+            w.p_old = s.dec;
+            w.p_new = decimated_prefix(g, j_new);
+            w.ew = plan_ewma(s.count, cur_stage_avg(h, k), j_new - s.segs);
+            const uint64_t m_old = w.p_old >> 3, m_new = w.p_new >> 3;
+            if (k == 0 && c.has_span()) {
+                // span by span, each exactly as a round of its own would split it: the buffer side
+                // (carried tail + seam: contiguous part for the first span, its seam region for the
+                // others) and the in-place side
+                uint64_t j_lo = w.j_old, m_lo = m_old;
+                const size_t ns = c.spans.size();
+                for (size_t i = 0; i < ns; ++i) {
+                    const DeviceSpan &sp = c.spans[i];
+                    const uint64_t first = sp.first;
+                    const uint64_t j_hi = i + 1 < ns ? segments_for(g, c.spans[i + 1].first) : j_new;
+                    const uint64_t m_hi = i + 1 < ns ? decimated_prefix(g, j_hi) >> 3 : m_new;
+                    uint64_t j_split =
+                        std::min<uint64_t>(j_hi, std::max<uint64_t>(j_lo, (first + g.hop - 1) / g.hop));
+                    uint64_t m_split =
+                        std::min<uint64_t>(m_hi, std::max<uint64_t>(m_lo, (first + HBF_HALO + 7) / 8));
+                    if (fast_ok && j_lo > 0) {
+                        // fast path: the tail side gets a whole number of segment pairs and exactly their
+                        // decimator outputs; the in-place side starts >= need_pre samples into the span
+                        uint64_t js = std::max<uint64_t>(j_lo, (first + need_pre + (single ? half : 0) + g.hop - 1) / g.hop);
+                        if (!single && ((js - j_lo) & 1))
+                            js += 1;
+                        if (js < j_hi && run_new0(js) <= first + seam && sp.len >= seam) {
+                            j_split = js;
+                            m_split = std::min<uint64_t>(m_hi, run_new0(js) / 8);
+                        }
+                    }
+                    if (j_split > j_lo || m_split > m_lo) {
+                        if (i == 0)
+                            w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, j_lo, j_split, m_lo, m_split, false};
+                        else
+                            w.spans[w.nspans++] = {s.buf.p[s.buf.cur] + regions[ci][i].off, regions[ci][i].base,
+                                                   j_lo, j_split, m_lo, m_split, true};
+                    }
+                    if (j_hi > j_split || m_hi > m_split) {
+                        Span ip{sp.d_x, first, j_split, j_hi, m_split, m_hi, true};
+                        if (sp.framed()) {
+                            ip.fpool = pool_fspan(h, sp.fs);
+                            ip.fch = sp.fch;
+                        }
+                        w.spans[w.nspans++] = ip;
+                    }
+                    j_lo = j_hi;
+                    m_lo = m_hi;
+                }
+            } else {
+                w.spans[w.nspans++] = {s.buf.p[s.buf.cur], s.buf.base, w.j_old, j_new, m_old, m_new, false};
+            }
+            works.push_back(w);
+        }
+    }
+    if (works.empty()) {
+        for (auto &c : h->ch) {
+            if (c.has_span())
+                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
+            c.submitted = false;
+        }
+        return PSDC_OK;
+    }
+    *did_work = true;
+
+    // where every stream will start after this round (its tail is carried to the
+    // front of its other buffer; the decimator appends the new samples behind it)
+    auto kf_after = [&](uint32_t ci, uint32_t k) -> uint64_t {
+        StageState t = h->ch[ci].st[k];
+        for (auto &w : works)
+            if (w.c == ci && w.k == k) {
+                t.segs = w.j_new;
+                t.dec = w.p_new;
+            }
+        return keep_from(g, t);
+    };
+    for (auto &w : works) {
+        Channel &c = h->ch[w.c];
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        if (t_next > 0) {
+            if (c.st.size() <= (size_t)w.k + 1) {
+                int rc = add_stage(h, c);
+                if (rc)
+                    return rc;
+            }
+            StageState &nx = c.st[w.k + 1];
+            // Rounds hold 1 ... PSDC_OPT_COALESCE in-place spans, and stage j sees a round's samples j rounds
+            // later: when a stream has to grow it grows at once to what the LARGEST round will bring it
+            // (longest span seen x the coalescing depth once a round has coalesced, / 8^j), not round size by
+            // round size -- every growth is two allocations and a copy in the middle of a live stream.
+            const size_t need = (size_t)(t_next - kf_after(w.c, w.k + 1));
+            size_t grow_to = 0;
+            if (c.span_max) {
+                const uint64_t round_max = (uint64_t)c.span_max * (c.coalesced_seen ? coalesce_limit(h, c) : 1);
+                const unsigned sh = 3u * (w.k + 1);
+                grow_to = (size_t)(sh < 64 ? round_max >> sh : 0) + (size_t)4 * (h->n + HBF_HALO) + 64;
+            }
+            int rc = ensure_cap(h, nx, need, grow_to);
+            if (rc)
+                return rc;
+        }
+    }
+    // stream buffers may have been reallocated by ensure_room: refresh span pointers
+    for (auto &w : works) {
+        StageState &s = h->ch[w.c].st[w.k];
+        for (int i = 0; i < w.nspans; ++i)
+            if (!w.spans[i].fixed) {
+                w.spans[i].src = s.buf.p[s.buf.cur];
+                w.spans[i].src_base = s.buf.base;
+            }
+    }
+
+    // ---- turn the work into kernel jobs ---------------------------------
+    // Fast path (fused_kernel / bigfused_kernel): whole segment pairs of a Hann stream with
+    // N = 256 ... 16384, any implemented detrend, plain-sum or EWMA averaging, 16-byte aligned.
+    // Everything else -- other N, the rectangular window, an odd last segment, the decimator
+    // ranges a pair does not cover (the first segment of a stream is decimated whole,
+    // src/psd.rs:235-238; outputs still inside the drain; unaligned zero-copy spans) -- goes
+    // through the generic welch / hbf_dec8 kernels.  Both write the same partial slab and
+    // next-stage stream, so the reduce and the bookkeeping do not care which ran.
+    struct PlanFused { FusedJob j; size_t work; };
+    struct PlanSeg { SegJob j; size_t work; };
+    std::vector<PlanFused> fjobs;
+    std::vector<PlanSeg> sjobs;
+    std::vector<DecJob> djobs;
+    uint64_t prof_samples = 0, prof_samples0 = 0;
+    for (size_t wi = 0; wi < works.size(); ++wi) {
+        Work &w = works[wi];
+        Channel &c = h->ch[w.c];
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        StageState *nx = t_next > 0 ? &c.st[w.k + 1] : nullptr;
+        const uint64_t nx_base = nx ? kf_after(w.c, w.k + 1) : 0;
+        auto add_dec = [&](const Span &sp, uint64_t ma, uint64_t mb) {
+            if (mb <= ma || mb <= g.drain || !nx)
+                return;
+            DecJob dj{};
+            dj.src = sp.src;
+            dj.fspan = sp.fpool;
+            dj.fch = sp.fch;
+            dj.src_base = (long long)sp.src_base;
+            dj.m0 = (long long)ma;
+            dj.dst = nx->buf.p[nx->buf.cur ^ 1];
+            dj.dst_base = (long long)nx_base;
+            dj.nout = (int)(mb - ma);
+            djobs.push_back(dj);
+        };
+        auto add_seg = [&](const Span &sp, uint64_t sa, uint64_t sb) {
+            if (sb <= sa)
+                return;
+            SegJob sj{};
+            sj.src = sp.src;
+            sj.fspan = sp.fpool;
+            sj.fch = sp.fch;
+            sj.src_base = (long long)sp.src_base;
+            sj.seg0 = (long long)sa;
+            sj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                              : -std::numeric_limits<double>::infinity();
+            sj.nseg = (int)(sb - sa);
+            sj.ntiles = (int)((sb - sa + spt - 1) / spt);
+            sj.step0 = (int)(sa - w.j_old) + 1;
+            sj.nb = (int)w.ew.nb;
+            sj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+            sj.ewma = w.ew.ewma ? 1 : 0;
+            sjobs.push_back({sj, wi});
+        };
+        for (int i = 0; i < w.nspans; ++i) {
+            const Span &sp = w.spans[i];
+            // first fused segment: far enough into the stream that every output survives the drain
+            uint64_t fs = sp.seg_a;
+            while (run_new0(fs) / 8 < g.drain)
+                fs += fstep;
+            const bool framed = sp.fpool >= 0;
+            uint64_t np = (fast_ok && nx && fs + fstep <= sp.seg_b && (!framed || (!single && fused_frames_supported((int)h->n))))
+                              ? (sp.seg_b - fs) / fstep : 0;
+            if (single && np) {
+                if (run_src0(fs) < sp.src_base) // (the half chunk in front of the first segment is not in this source)
+                    np = 0;
+                if (dbl)
+                    np &= ~(uint64_t)1; // (an odd last segment goes to the generic kernels)
+            }
+            const uint64_t fofs = np ? run_src0(fs) - sp.src_base : 0; // samples of this span in front of the pairs' source
+            const float *fsrc = framed ? nullptr : sp.src + fofs;
+            const uint64_t mf0 = run_new0(fs) / 8, mf1 = mf0 + (h->n / 8) * np;
+            const bool aligned = framed ? (fofs & 3u) == 0 : (reinterpret_cast<uintptr_t>(fsrc) & 15u) == 0;
+            if (np && (!aligned || mf0 < sp.m_a || mf1 > sp.m_b || (fofs < need_pre && sp.src_base != 0)))
+                np = 0;
+            if (np) {
+                FusedJob fj{};
+                // (a frame job never reads through src, but the kernels form per-lane pointers from it before they know: keep that
+                // arithmetic off a null pointer -- any valid device address will do)
+                fj.src = framed ? h->d_win : fsrc;
+                fj.fspan = sp.fpool;
+                fj.fch = sp.fch;
+                fj.s_off = framed ? (unsigned)fofs : 0u;
+                fj.dst = nx->buf.p[nx->buf.cur ^ 1] + (mf0 - g.drain - nx_base);
+                fj.npairs = (int)np;
+                fj.pre = (int)std::min<uint64_t>(fofs, HBF_HALO);
+                fj.log2_gamma = w.ew.gamma > 0.0f ? std::log2((double)w.ew.gamma)
+                                                  : -std::numeric_limits<double>::infinity();
+                fj.step0 = (int)(fs - w.j_old) + 1;
+                fj.nb = (int)w.ew.nb;
+                fj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
+                fj.ewma = w.ew.ewma ? 1 : 0;
+                fjobs.push_back({fj, wi});
+                add_seg(sp, sp.seg_a, fs);
+                add_seg(sp, fs + fstep * np, sp.seg_b);
+                add_dec(sp, sp.m_a, mf0);
+                add_dec(sp, mf1, sp.m_b);
+            } else {
+                add_seg(sp, sp.seg_a, sp.seg_b);
+                add_dec(sp, sp.m_a, sp.m_b);
+            }
+        }
+        prof_samples += w.p_new - w.p_old;
+        if (w.k == 0)
+            prof_samples0 += w.p_new - w.p_old;
+    }
+
+    // share the persistent workgroups so that every workgroup walks about the same amount
+    // shares are computed per launch batch (MAX_JOBS jobs): every launch fills the GPU by itself
+    size_t blocks_total = 0;
+    for (size_t b0 = 0; b0 < sjobs.size(); b0 += MAX_JOBS) {
+        const size_t b1 = std::min(sjobs.size(), b0 + (size_t)MAX_JOBS);
+        size_t tiles = 0;
+        for (size_t i = b0; i < b1; ++i)
+            tiles += (size_t)sjobs[i].j.ntiles;
+        const size_t per = std::max<size_t>(1, (tiles + WELCH_MAX_BLOCKS - 1) / WELCH_MAX_BLOCKS);
+        for (size_t i = b0; i < b1; ++i) {
+            sjobs[i].j.nblocks = (int)(((size_t)sjobs[i].j.ntiles + per - 1) / per);
+            blocks_total += (size_t)sjobs[i].j.nblocks;
+        }
+    }
+    const uint64_t teams = (uint64_t)std::max(1, fused_pairs_per_block((int)h->n, 1));
+    // Jobs that read frames in place go first in their launch, the four traces of one span side by side (same span, same
+    // offset: the same geometry, hence equal workgroup counts): the kernel deals such a group's workgroups over the XCDs so
+    // that the four readers of the same bytes share an L2 (FusedBatch::fg_*).
+    bool any_frames = false;
+    for (const PlanFused &pf : fjobs)
+        any_frames = any_frames || pf.j.fspan >= 0;
+    if (any_frames)
+        std::stable_sort(fjobs.begin(), fjobs.end(), [](const PlanFused &a, const PlanFused &b) {
+            const bool fa = a.j.fspan >= 0, fb = b.j.fspan >= 0;
+            if (fa != fb)
+                return fa;
+            if (!fa)
+                return false;
+            if (a.j.fspan != b.j.fspan)
+                return a.j.fspan < b.j.fspan;
+            if (a.j.s_off != b.j.s_off)
+                return a.j.s_off < b.j.s_off;
+            return a.j.fch < b.j.fch;
+        });
+    for (size_t b0 = 0; b0 < fjobs.size(); b0 += MAX_JOBS) {
+        const size_t b1 = std::min(fjobs.size(), b0 + (size_t)MAX_JOBS);
+        // One run length R for the whole launch: the smallest R for which the jobs' workgroups
+        // (ceil(pairs / (R teams)) each) fit the resident capacity.  A launch that asks for more
+        // workgroups than are resident at once runs the surplus as a second wave behind the first.
+        // (A launch that reads frames leaves a few workgroup slots free: the header scan of the NEXT call runs on a
+        // side stream while this launch is resident, and would otherwise wait for it to drain.)
+        bool batch_frames = false;
+        for (size_t i = b0; i < b1; ++i)
+            batch_frames = batch_frames || fjobs[i].j.fspan >= 0;
+        // (FRAME_RESERVE_BLOCKS slots of at least 256 threads' worth of registers each)
+        const uint64_t reserve = (uint64_t)FRAME_RESERVE_BLOCKS * (uint64_t)std::max(1, 256 / std::max(1, fused_block_threads((int)h->n)));
+        const uint64_t max_blocks = (uint64_t)fused_max_blocks((int)h->n);
+        const uint64_t cap_slots = max_blocks > reserve + 1 && batch_frames ? max_blocks - reserve : max_blocks;
+        // Small jobs ride on top: a job whose one workgroup has at most a quarter of a full workgroup's work (the deep stages
+        // of every channel: a handful of pairs per round) does not count against the capacity.  Its workgroup goes FIRST in
+        // the grid, is resident for a few microseconds and leaves its slot to one of the surplus workgroups of the large
+        // jobs, so the launch asks for cap + (small jobs) workgroups and ends about one small job later than a launch of
+        // the large jobs alone -- where counting them against the capacity left their slots empty for nearly the whole launch
+        // (8 channels x 8 deep stages: 64 of 512 slots).
+        static const bool no_oversub = getenv("PSDC_NO_OVERSUB") != nullptr; // (A/B aid)
+        auto small_at = [&](uint64_t np, uint64_t r) { return !no_oversub && 4 * np <= r * teams; };
+        auto plan_r = [&](uint64_t r_small) { // the smallest R whose LARGE jobs fit the capacity, given which jobs count as small
+            uint64_t pairs = 0, nlarge = 0;
+            for (size_t i = b0; i < b1; ++i)
+                if (!small_at((uint64_t)fjobs[i].j.npairs, r_small)) {
+                    pairs += (uint64_t)fjobs[i].j.npairs;
+                    ++nlarge;
+                }
+            // (every job holds at least one workgroup: with more large jobs than slots -- MAX_JOBS = 128 against >= 248 slots, so
+            // only under the CPU model's artificially small capacities -- the search below would never end)
+            const uint64_t cap = std::max<uint64_t>(cap_slots, nlarge);
+            auto blocks_at = [&](uint64_t r) {
+                uint64_t nb = 0;
+                for (size_t i = b0; i < b1; ++i)
+                    if (!small_at((uint64_t)fjobs[i].j.npairs, r_small))
+                        nb += ((uint64_t)fjobs[i].j.npairs + r * teams - 1) / (r * teams);
+                return nb;
+            };
+            uint64_t r = std::max<uint64_t>(1, (pairs + cap * teams - 1) / (cap * teams));
+            while (blocks_at(r) > cap)
+                ++r;
+            return r;
+        };
+        uint64_t R = plan_r(0); // every job counted
+        for (int it = 0; it < 3; ++it) {
+            const uint64_t rn = plan_r(R);
+            if (rn == R)
+                break;
+            R = rn;
+        }
+        // $PSDC_DBG_FIXED_RUN=<pairs> (measurement aid): ONE run length whatever the launch holds -- what run boundaries that are a
+        // function of the absolute pair index (chunk-invariant grouping of the partial sums, include/psdcascade.h Conventions)
+        // would cost: launches then ask for more or fewer workgroups than are resident at once.  Results stay correct.
+        static const uint64_t fixed_run = getenv("PSDC_DBG_FIXED_RUN") ? strtoull(getenv("PSDC_DBG_FIXED_RUN"), nullptr, 10) : 0;
+        if (fixed_run)
+            R = fixed_run;
+        for (size_t i = b0; i < b1; ++i) {
+            FusedJob &j = fjobs[i].j;
+            const uint64_t np = (uint64_t)j.npairs;
+            const uint64_t nb = small_at(np, R) ? 1 : (np + R * teams - 1) / (R * teams);
+            uint64_t run = (np + nb * teams - 1) / (nb * teams); // evened out within the job (<= R)
+            if (dbl)
+                run += run & 1; // every team starts on an even segment and holds whole segment pairs
+            j.run = (int)run;
+            j.nblocks = (int)((np + run * teams - 1) / (run * teams));
+            blocks_total += (size_t)j.nblocks;
+        }
+        // small jobs first in the grid (stable: the frame groups stay together behind them)
+        std::stable_partition(fjobs.begin() + (std::ptrdiff_t)b0, fjobs.begin() + (std::ptrdiff_t)b1,
+                              [&](const PlanFused &pf) { return small_at((uint64_t)pf.j.npairs, R); });
+    }
+    int rc = ensure_partial(h, blocks_total * h->n);
+    if (rc)
+        return rc;
+    // slab: the partials of one work are contiguous (fused first, then generic)
+    std::vector<RedJob> rjobs(works.size());
+    {
+        // (the jobs of a work need not be adjacent in fjobs: frame jobs were moved to the front)
+        std::vector<size_t> nblk(works.size(), 0), base(works.size(), 0);
+        for (const PlanFused &pf : fjobs)
+            nblk[pf.work] += (size_t)pf.j.nblocks;
+        for (const PlanSeg &ps : sjobs)
+            nblk[ps.work] += (size_t)ps.j.nblocks;
+        size_t slab = 0;
+        for (size_t wi = 0; wi < works.size(); ++wi) {
+            RedJob &rj = rjobs[wi];
+            base[wi] = slab;
+            rj.partial = h->d_partial + slab;
+            rj.spectrum = h->ch[works[wi].c].st[works[wi].k].spectrum;
+            rj.g_total = (float)works[wi].ew.g_total;
+            rj.nparts = (int)nblk[wi];
+            slab += nblk[wi] * h->n;
+        }
+        if (slab > h->partial_cap)
+            return fail(h, PSDC_ERR_DEVICE, "internal: partial slab overflow");
+        for (PlanFused &pf : fjobs) {
+            pf.j.partial = h->d_partial + base[pf.work];
+            base[pf.work] += (size_t)pf.j.nblocks * h->n;
+        }
+        for (PlanSeg &ps : sjobs) {
+            ps.j.partial = h->d_partial + base[ps.work];
+            base[ps.work] += (size_t)ps.j.nblocks * h->n;
+        }
+    }
+
+    // ---- launches: fused, generic welch, reduce, generic decimator -------
+    // HIP events time the dominant kernel of the round (fused when present).  The fused launches
+    // hand their events to hipExtLaunchKernelGGL, which stamps the kernel's own start and stop (what
+    // rocprofv3 --kernel-trace reports); events recorded around a launch would include the ~6 us
+    // dependent-dispatch gap in front of it.  The generic welch kernel keeps the bracket.
+    const bool prof_fused = fast_ok; // the handle's dominant kernel kind, not the round's
+    auto prof_begin = [&](ProfEvents &pe, bool record) -> int {
+        if (!h->profile)
+            return PSDC_OK;
+        HIPCHK(h, hipEventCreate(&pe.a));
+        HIPCHK(h, hipEventCreate(&pe.b));
+        if (record)
+            HIPCHK(h, hipEventRecord(pe.a, h->stream));
+        return PSDC_OK;
+    };
+    auto prof_end = [&](ProfEvents &pe, bool first, bool record) -> int {
+        if (!h->profile)
+            return PSDC_OK;
+        if (record)
+            HIPCHK(h, hipEventRecord(pe.b, h->stream));
+        h->prof_pending.push_back(pe);
+        h->prof.launches += 1;
+        if (first) {
+            h->prof.samples += prof_samples;
+            h->prof.stage0_samples += prof_samples0;
+        }
+        return PSDC_OK;
+    };
+    for (size_t i = 0; i < fjobs.size();) {
+        FusedBatch fb{};
+        fb.detrend = h->detrend;
+        fb.single = dbl ? 2 : single ? 1 : 0;
+        FspanMap fm(fb.fspans);
+        for (; i < fjobs.size() && fb.njobs < MAX_JOBS; ++i) {
+            FusedJob j = fjobs[i].j;
+            j.block_begin = fb.nblocks;
+            fb.nblocks += j.nblocks;
+            fb.any_ewma |= j.ewma;
+            if (j.fspan >= 0) {
+                fb.any_frames = 1;
+                if ((j.fspan = fm.map(h, j.fspan)) < 0)
+                    return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
+            }
+            fb.jobs[fb.njobs++] = j;
+        }
+        static const bool no_groups = getenv("PSDC_DBG_NOGROUPS") != nullptr; // (debugging aid)
+        for (int a = 0; !no_groups && a + 3 < fb.njobs && fb.n_fgroups < MAX_FSPANS; ) { // the four traces of one span, side by side
+            const FusedJob *q = fb.jobs + a;
+            const bool group = q[0].fspan >= 0 && q[0].fch == 0 && q[1].fch == 1 && q[2].fch == 2 && q[3].fch == 3 &&
+                               q[1].fspan == q[0].fspan && q[2].fspan == q[0].fspan && q[3].fspan == q[0].fspan &&
+                               q[1].s_off == q[0].s_off && q[2].s_off == q[0].s_off && q[3].s_off == q[0].s_off &&
+                               q[1].nblocks == q[0].nblocks && q[2].nblocks == q[0].nblocks && q[3].nblocks == q[0].nblocks;
+            if (!group) {
+                ++a;
+                continue;
+            }
+            fb.fg_begin[fb.n_fgroups] = q[0].block_begin;
+            fb.fg_nb[fb.n_fgroups] = q[0].nblocks;
+            ++fb.n_fgroups;
+            a += 4;
+        }
+        ProfEvents pe{};
+        const bool first = (i <= (size_t)MAX_JOBS);
+        if ((rc = prof_begin(pe, false)))
+            return rc;
+        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b));
+        if ((rc = prof_end(pe, first, false)))
+            return rc;
+    }
+    for (size_t i = 0; i < sjobs.size();) {
+        WelchBatch wb{};
+        wb.hop = (int)g.hop;
+        wb.detrend = h->detrend;
+        FspanMap fm(wb.fspans);
+        for (; i < sjobs.size() && wb.njobs < MAX_JOBS; ++i) {
+            SegJob j = sjobs[i].j;
+            if (j.fspan >= 0 && (j.fspan = fm.map(h, j.fspan)) < 0)
+                return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
+            j.block_begin = wb.nblocks;
+            wb.nblocks += j.nblocks;
+            wb.jobs[wb.njobs++] = j;
+        }
+        ProfEvents pe{};
+        const bool first = (i <= (size_t)MAX_JOBS);
+        if (!prof_fused && (rc = prof_begin(pe, true)))
+            return rc;
+        if (bigfft_size((int)h->n))
+            HIPCHK(h, launch_welch_big((int)h->n, wb, h->d_win, h->d_tw, h->d_bigfft, h->bigfft_elems, h->bigfft_chunk_limit, h->stream));
+        else
+            HIPCHK(h, launch_welch((int)h->n, wb, h->d_win, h->d_tw, h->d_chirp, h->d_bhat, h->stream));
+        if (!prof_fused && (rc = prof_end(pe, first, true)))
+            return rc;
+    }
+    for (size_t i = 0; i < djobs.size();) {
+        DecBatch db{};
+        db.drain = (int)g.drain;
+        FspanMap fm(db.fspans);
+        for (; i < djobs.size() && db.njobs < MAX_JOBS; ++i) {
+            DecJob j = djobs[i];
+            if (j.fspan >= 0 && (j.fspan = fm.map(h, j.fspan)) < 0)
+                return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
+            j.tile_begin = db.ntiles;
+            db.ntiles += (j.nout + DEC_TILE - 1) / DEC_TILE;
+            db.jobs[db.njobs++] = j;
+        }
+        HIPCHK(h, launch_dec(db, h->stream));
+    }
+
+    // bookkeeping: counts and stream positions
+    std::vector<std::vector<uint64_t>> old_total(h->n_channels);
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci)
+        for (auto &s : h->ch[ci].st)
+            old_total[ci].push_back(s.total);
+    for (auto &w : works) {
+        StageState &s = h->ch[w.c].st[w.k];
+        s.count64 = count_after64(s.count64, cur_stage_avg(h, w.k), w.j_new - w.j_old);
+        s.count = count_report(s.count64);
+        s.segs = w.j_new;
+        s.dec = w.p_new;
+    }
+    for (auto &w : works) {
+        const uint64_t t_next = emitted_for(g, w.p_new);
+        if (t_next > 0)
+            h->ch[w.c].st[w.k + 1].total = t_next; // visible to the next stage from the next round on
+    }
+
+    // carry the small tail [keep_from, old total) of every stream that consumed or
+    // received samples to the front of its other buffer, then swap
+    std::vector<TailJob> tjobs;
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        Channel &c = h->ch[ci];
+        for (uint32_t k = 0; k < c.st.size(); ++k) {
+            StageState &s = c.st[k];
+            const uint64_t kf = keep_from(g, s);
+            const uint64_t told = old_total[ci][k];
+            const bool received = s.total != told;
+            if (kf == s.buf.base && !received && s.buf.end == s.total)
+                continue;
+            const bool span0 = (k == 0 && c.has_span());
+            const DeviceSpan last = span0 ? c.spans.back() : DeviceSpan{};
+            const uint64_t cnt = told > kf ? told - kf : 0;
+            if (span0 && kf < last.first)
+                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span tail not in the span");
+            if (s.total - kf > s.buf.cap)
+                return fail(h, PSDC_ERR_DEVICE, "internal: tail exceeds stream buffer");
+            const int other = s.buf.cur ^ 1;
+            if (cnt && span0) {
+                tjobs.push_back(span_copy(h, last, kf, s.buf.p[other], (size_t)cnt));
+            } else if (cnt) {
+                TailJob t{};
+                t.src = s.buf.p[s.buf.cur] + (kf - s.buf.base);
+                t.dst = s.buf.p[other];
+                t.count = (int)cnt;
+                tjobs.push_back(t);
+            }
+            s.buf.cur = other;
+            s.buf.base = kf;
+            s.buf.end = s.total;
+        }
+    }
+    // epilogue (fold the partials, carry the tails): deferred to the next launch_deferred()
+    h->pend_red = std::move(rjobs);
+    h->pend_tail = std::move(tjobs);
+    for (auto &c : h->ch) {
+        c.spans.clear();
+        c.submitted = false;
+    }
+    return PSDC_OK;
+}
+
+// one pipeline round (ingest path)
+int advance(psdc_handle *h)
+{
+    bool did = false;
+    return advance_round(h, &did, false);
+}
+
+// rounds until the pipeline is idle (read-out path)
+int drain(psdc_handle *h)
+{
+    if (h->idle)
+        return PSDC_OK;
+    for (int guard = 0; guard < 64; ++guard) {
+        bool did = false;
+        int rc = advance_round(h, &did, true);
+        if (rc)
+            return rc;
+        if (!did) {
+            h->idle = true;
+            return PSDC_OK;
+        }
+    }
+    return fail(h, PSDC_ERR_DEVICE, "internal: pipeline did not drain");
+}
+
+} // namespace psdrt

@@ -1,4 +1,4 @@
-// tests/host/round_plan_check.cpp -- the library's host runtime (stabilizer-stream_amd/csrc/psdcascade.cpp, UNCHANGED: the
+// tests/host/round_plan_check.cpp -- the library's host runtime (stabilizer-stream_amd/csrc/{runtime,planner,frames_ingest,readout}.cpp, UNCHANGED: the
 // round planner advance_round, the staging / upload pipeline, frame ingest, read-outs) on the CPU, under AddressSanitizer and
 // UBSan, against a host model of the HIP runtime and of the kernels (tests/host/sim/).  TEST INFRASTRUCTURE.
 //

@@ -1,6 +1,6 @@
 // tests/host/sim/hip/hip_runtime.h -- TEST INFRASTRUCTURE, never part of the product.
 //
-// A host model of the handful of HIP runtime calls stabilizer-stream_amd/csrc/psdcascade.cpp makes, so that the library's
+// A host model of the handful of HIP runtime calls the host runtime (stabilizer-stream_amd/csrc/{runtime,planner,frames_ingest,readout}.cpp) makes, so that the library's
 // whole host runtime -- the round planner above all (advance_round: span splitting, seam regions, deferral, run sizing, tail
 // carries, buffer growth) -- runs on the CPU under AddressSanitizer / UBSan (tests/host/round_plan_check.cpp).  "Device
 // memory" is malloc'ed host memory, so every address the planner hands to a kernel is checked by ASan when the modelled

@@ -1,5 +1,5 @@
 // tests/host/sim/sim_kernels.cpp -- TEST INFRASTRUCTURE: host models of the kernel launchers of csrc/kernels.h, linked with
-// the library's host runtime (csrc/psdcascade.cpp, unchanged) in tests/host/round_plan_check.  See sim_device.h for what the
+// the library's host runtime (csrc/{runtime,planner,frames_ingest,readout}.cpp, unchanged) in tests/host/round_plan_check.  See sim_device.h for what the
 // models track.  Each model names the real kernel whose memory accesses it reproduces.
 #include "kernels.h"
 

@@ -65,7 +65,7 @@ def test_host_programs(pkg):
 
 @pytest.mark.timeout(900)
 def test_round_planner_on_the_cpu_under_sanitizers():
-    """tests/host/round_plan_check: the library's host runtime (csrc/psdcascade.cpp unchanged -- the round planner
+    """tests/host/round_plan_check: the library's host runtime (csrc/runtime.cpp, planner.cpp, frames_ingest.cpp, readout.cpp unchanged -- the round planner
     advance_round, staging, frame ingest, read-outs) linked with a host model of the HIP runtime and of the kernels
     (tests/host/sim/), built with -fsanitize=address,undefined.  The GPU fuzz campaigns' feeds are replayed; every address
     the planner hands to a kernel is touched as the real kernel touches it, and every segment and every decimator output
