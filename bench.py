@@ -365,7 +365,8 @@ def main():
     ap.add_argument("--window", default="hann", choices=["hann", "rectangular", "hamming"],
                     help="hann (the configs'), rectangular (overlap 0: the fused kernels, two disjoint segments per transform) or a caller-built Hamming table with overlap N/2")
     ap.add_argument("--coalesce", type=int, default=None,
-                    help="PSDC_OPT_COALESCE: in-place spans that may share a round while the device is busy (library default 8)")
+                    help="PSDC_OPT_COALESCE: in-place spans of a channel that share a round (library default 8; 16 for one channel fed in spans <= 2^25)")
+    ap.add_argument("--eager", action="store_true", help="PSDC_OPT_EAGER: held spans go out when the device is seen idle (timing-dependent rounds; A/B aid)")
     ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -448,6 +449,8 @@ def main():
     bank.set_detrend(pkg.Detrend[args.detrend.upper()])
     if args.coalesce is not None:
         bank.configure(coalesce=args.coalesce)
+    if args.eager:
+        bank.configure(eager=True)
     if args.min_pairs is not None:
         bank.configure(min_pairs=args.min_pairs)
     if args.avg:
@@ -499,6 +502,8 @@ def main():
         scratch.set_detrend(pkg.Detrend[args.detrend.upper()])
         if args.coalesce is not None:
             scratch.configure(coalesce=args.coalesce)
+        if args.eager:
+            scratch.configure(eager=True)
         if args.min_pairs is not None:
             scratch.configure(min_pairs=args.min_pairs)
         scratch.configure(profile=True)  # rocprofv3 --stats sees these launches too: counted in *_whole_process

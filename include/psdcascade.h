@@ -26,7 +26,13 @@
  *     segment after segment into one f32 accumulator and is bit-identical under any chunking; here the segments a call brings
  *     are summed in groups (per workgroup run in f32, across runs in f64, one f32 add into the accumulator per round) whose
  *     boundaries follow the calls, so two chunkings of one stream agree to <= 2e-6 relative per bin (asserted by
- *     tests/test_gpu_parity.py::test_chunking_invariance), while the same stream fed by the same calls is bit-reproducible.
+ *     tests/test_gpu_parity.py::test_chunking_invariance).  The same stream fed by the same CALLS is bit-reproducible, run to
+ *     run and whatever the host's timing (tests/test_gpu_parity.py::test_same_calls_same_bits: the same spans with sleeps
+ *     injected between the calls): which device spans share a round -- hence the grouping of the sums -- is decided by the call
+ *     sequence alone (PSDC_OPT_COALESCE), never by how busy the device happens to be.  Only a handle switched to
+ *     PSDC_OPT_EAGER gives that up: its held spans go out as soon as the device is seen idle, so its round composition
+ *     follows host timing and repeated runs agree to the same <= 2e-6, not to the bit (host-fed samples and one-span feeds
+ *     stay bit-reproducible there too).
  *     Either grouping is closer to the exact sum than the reference's sequential f32 accumulation.
  */
 #ifndef PSDCASCADE_H
@@ -74,10 +80,17 @@ extern "C" {
 
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
-#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that may share one round while the device is
-                             * still busy with earlier ones (1..16; default: 8, and 16 for a single channel fed in spans of
-                             * at most 2^25 samples -- a round costs ~20 us whatever it holds; 1 = every span its own round;
-                             * -k: hold k spans back even on an idle device -- for tests) */
+#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8, and 16 for a single
+                             * channel fed in spans of at most 2^25 samples -- a round costs ~20 us whatever it holds; 1 = every
+                             * span its own round).  A span is HELD until its channel holds that many or a call arrives that
+                             * cannot join them (host-fed or short spans, settings changes, every read-out, psdc_flush, psdc_sync,
+                             * psdc_record_consumed): which spans share a round depends on the calls alone, so results are
+                             * bit-reproducible.  Held spans are caller memory the library has not read yet: the rule of
+                             * psdc_process_device (unmodified until sync / read-out / consumed event) covers them.
+                             * (-k is accepted and means k: through ABI 3's first builds it asked for exactly this hold.) */
+#define PSDC_OPT_EAGER 5 /* 1: a held span also goes out as soon as the device is seen idle (hipStreamQuery) -- the first span of a
+                          * burst starts at once instead of waiting for its round to fill, at the price of a round composition
+                          * that follows host timing: repeated runs then agree to rounding (<= 2e-6), not to the bit.  Default 0. */
 #define PSDC_OPT_PROFILE 2 /* 1: time the dominant kernel with HIP events (psdc_profile_read) */
 #define PSDC_OPT_MIN_PAIRS 4 /* segment pairs a decimated stage (k >= 1) collects before it issues work on the ingest
                               * path (default 32 x teams per workgroup: 256 at n = 1024; 0 = issue at once).  Read-outs,

@@ -341,7 +341,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
             const uint8_t *piece = d_frames + f0 * frame_size;
             if (in_place_ok && per_ch >= (size_t)4 * (h->n + HBF_HALO)) {
                 // The four traces are read IN PLACE, as wire words, by the stage-0 loads of the fused kernel: a zero-copy span
-                // per trace, exactly like psdc_process_device's -- held back while the device is busy so that calls share rounds.
+                // per trace, exactly like psdc_process_device's -- held back so that calls share rounds (the same rule: runtime.cpp coalesce_limit).
                 bool flush = false;
                 for (int ci = 0; ci < 4; ++ci) {
                     Channel &c = h->ch[ci];
@@ -381,7 +381,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                     if (c.spans.size() > 1)
                         c.coalesced_seen = true;
                 }
-                // on an idle device nothing is held back; on a busy one the next call may share this one's round
+                // held until PSDC_OPT_COALESCE calls share the round (an eager handle: until the device is seen idle)
                 if (h->ch[0].spans.size() >= h->coalesce || device_idle(h)) {
                     rc = advance(h);
                     if (rc)

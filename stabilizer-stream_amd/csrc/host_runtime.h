@@ -160,7 +160,7 @@ struct psdc_handle {
     bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or MAX_COALESCE for one channel fed in short spans (coalesce_limit)
     uint32_t stage_limit = psdrt::MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
-    bool coalesce_always = false; // hold them back even when the device is idle (tests)
+    bool eager = false; // PSDC_OPT_EAGER: a held span goes out as soon as the device is seen idle (round composition then follows host timing)
     bool profile = false;
     std::vector<psdrt::ProfEvents> prof_pending;
     psdc_profile prof{};

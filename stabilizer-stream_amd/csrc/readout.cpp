@@ -279,7 +279,7 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->profile = h->profile;
     o->coalesce = h->coalesce;
     o->coalesce_auto = h->coalesce_auto;
-    o->coalesce_always = h->coalesce_always;
+    o->eager = h->eager;
     o->stage_limit = h->stage_limit;
     o->min_pairs = h->min_pairs;
     auto bad = [&](const char *what) -> psdc_handle * {

@@ -453,11 +453,19 @@ int collect_profile(psdc_handle *h)
     return PSDC_OK;
 }
 
-// nothing of this handle is executing or queued on the device
 // In-place spans of a channel that may share a round.  A round costs ~20 us of launch boundaries whatever it holds (the post
 // launch and two dependent dispatches): 8 spans of 2^26 samples are 0.7 ms of kernel, 8 of 2^22 are 50 us -- so a single channel fed in
 // spans of at most 2^25 samples may hold sixteen (2^24 a call: +3 %, 2^22: +21 %; eight channels x 2^24 measured -2 % with sixteen and stay
 // at eight).  An explicit PSDC_OPT_COALESCE is taken as given.
+//
+// WHICH spans share a round is a function of the call sequence alone (round 5): a joinable span is held until its channel holds
+// `coalesce_limit` of them or a call arrives that cannot join (a host-fed or short span, a settings change, a read-out, psdc_flush /
+// psdc_sync / psdc_record_consumed).  Through round 4 a held span also went out as soon as hipStreamQuery saw the device idle: lower
+// latency on a trickle feed, but the grouping of the partial sums -- run lengths, the one f32 add per round -- then followed HOST
+// TIMING, and the same calls could give spectra that differ in the last bits from run to run (the driver's bench coalesced 6.8 spans
+// a launch where the builder's box made 7.9, same code, same calls).  The reference is deterministic to the bit (src/psd.rs:228-233);
+// so is the default here.  PSDC_OPT_EAGER = 1 brings the timing rule back for callers who want the first span of a burst on the
+// device at once.
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
 {
     if (h->coalesce_auto && h->n_channels == 1 && std::max(c.span_max, len) <= ((size_t)1 << 25))
@@ -465,7 +473,8 @@ uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
     return h->coalesce;
 }
 
-bool device_idle(psdc_handle *h) { return !h->coalesce_always && hipStreamQuery(h->stream) == hipSuccess; }
+// eager handles only: nothing of this handle is executing or queued on the device (~0.1 us, tools/probes/stream_query.cpp)
+bool device_idle(psdc_handle *h) { return h->eager && hipStreamQuery(h->stream) == hipSuccess; }
 
 int submit_host(psdc_handle *h, Channel &c)
 {
@@ -1004,7 +1013,7 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
         h->profile = value != 0;
         return PSDC_OK;
     case PSDC_OPT_COALESCE: {
-        const int64_t k = value < 0 ? -value : value; // negative: hold spans back even on an idle device
+        const int64_t k = value < 0 ? -value : value; // (-k: what "hold even on an idle device" was spelled through round 4; the default now)
         if (k < 1 || k > MAX_COALESCE)
             return fail(h, PSDC_ERR_ARG, "coalesce out of range (1..16)");
         int rc = flush_all(h);
@@ -1012,7 +1021,13 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
             return rc;
         h->coalesce = (uint32_t)k;
         h->coalesce_auto = false;
-        h->coalesce_always = value < 0;
+        return PSDC_OK;
+    }
+    case PSDC_OPT_EAGER: {
+        int rc = flush_all(h);
+        if (rc)
+            return rc;
+        h->eager = value != 0;
         return PSDC_OK;
     }
     case PSDC_OPT_MIN_PAIRS: {
@@ -1127,10 +1142,9 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     Channel &c = h->ch[channel];
     const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
-    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them, and a device that is still
-    // busy with earlier rounds (when it is idle nothing is ever held back).
-    // (the stream is asked at most ONCE per call -- ~0.1 us on an idle or a busy stream, tools/probes/stream_query.cpp; a "busy" answer
-    // stands for the rest of the call)
+    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them (coalesce_limit: the rule is a function of the calls
+    // alone).  An EAGER handle also sends them out when it sees the device idle (the stream is asked at most ONCE per call; a
+    // "busy" answer stands for the rest of the call).
     bool flush = c.submitted, known_busy = false;
     if (c.has_span()) {
         if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len))
@@ -1174,7 +1188,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     }
     if (h->n_channels == 1) {
         if (c.has_span() && !c.submitted && c.spans.size() < coalesce_limit(h, c) && (known_busy || !device_idle(h)))
-            return PSDC_OK; // the device is busy: the next span may share this one's round
+            return PSDC_OK; // held: the next span may share this one's round
         return advance(h);
     }
     return PSDC_OK;

@@ -189,7 +189,9 @@ void scenario_stress(uint64_t seed)
         xs.push_back(ident_stream(c, total));
     CK(psdc_configure(h, PSDC_OPT_QUANTUM, (int64_t)r.u(2, 20) * n));
     const int co[] = {1, 4, 8, 16, -2, -4, -8, -16};
-    CK(psdc_configure(h, PSDC_OPT_COALESCE, co[r.u(0, 8)]));
+    const int cov = co[r.u(0, 8)];
+    CK(psdc_configure(h, PSDC_OPT_COALESCE, cov));
+    CK(psdc_configure(h, PSDC_OPT_EAGER, cov > 0 ? 1 : 0)); // (positive: held spans also go out when the modelled stream is idle)
     if (r.f() < 0.5)
         CK(psdc_configure(h, PSDC_OPT_MIN_PAIRS, (int64_t)r.u(0, 40)));
     std::vector<uint64_t> pos((size_t)nch, 0);
@@ -275,7 +277,8 @@ void scenario_spans(uint64_t seed)
     std::vector<std::vector<float>> xs;
     for (int c = 0; c < nch; ++c)
         xs.push_back(ident_stream(c, total));
-    CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 17) * (r.f() < 0.6 ? -1 : 1)));
+    CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 17)));
+    CK(psdc_configure(h, PSDC_OPT_EAGER, r.f() < 0.4 ? 1 : 0)); // (eager: held spans go out when the modelled stream is idle)
     if (r.f() < 0.5)
         CK(psdc_configure(h, PSDC_OPT_MIN_PAIRS, (int64_t)r.u(0, 300)));
     std::vector<uint64_t> pos((size_t)nch, 0);
@@ -323,7 +326,8 @@ void scenario_frames(uint64_t seed)
     std::vector<uint8_t> moved(frames.size() + 16);
     uint8_t *base = moved.data() + ((8 - (reinterpret_cast<uintptr_t>(moved.data()) & 7)) & 7) + shift;
     memcpy(base, frames.data(), frames.size());
-    CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 9) * (r.f() < 0.5 ? -1 : 1)));
+    CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 9)));
+    CK(psdc_configure(h, PSDC_OPT_EAGER, r.f() < 0.5 ? 1 : 0));
     std::vector<std::vector<float>> xs;
     for (int c = 0; c < 4; ++c)
         xs.push_back(ident_stream(c, pre + 8));

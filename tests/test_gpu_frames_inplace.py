@@ -59,7 +59,7 @@ def test_frames_in_place(pkg, ora, gpu_required, n, batches, detrend):
 
 
 def test_frames_in_place_coalesced_and_mixed(pkg, ora, gpu_required):
-    """Calls that share rounds (held back as on a busy device: coalesce = -4), then the same channels fed host
+    """Calls that share rounds (held until four calls share a round: coalesce = 4), then the same channels fed host
     samples and an f32 device span behind the frames: one stream per trace whatever the source."""
     import torch
     n, batches = 4096, 22
@@ -68,7 +68,7 @@ def test_frames_in_place_coalesced_and_mixed(pkg, ora, gpu_required):
     buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=5)
     d = torch.from_numpy(buf.reshape(-1)).cuda()
     g = pkg.PsdCascadeBank(n, 4)
-    g.configure(coalesce=-4)
+    g.configure(coalesce=4)
     step = nframes // 6
     for a in range(0, 6 * step, step):
         assert g.process_adcdac_frames_device(d.data_ptr() + a * fs, fs, step) == step

@@ -645,16 +645,17 @@ def test_past_the_u32_gain_overflow(pkg, gpu_required):
 @pytest.mark.parametrize("n,coalesce", [(1024, -2), (1024, -4), (1024, -8), (512, -3), (4096, -4), (1024, 4), (1024, -16), (256, -13), (8192, -16)])
 def test_coalesced_spans(pkg, ora, gpu_required, n, coalesce):
     """PSDC_OPT_COALESCE: several in-place device spans of one channel go out as ONE round (each
-    with its own seam region between it and the span before).  Negative values hold spans back even
-    on an idle device, so the multi-span planner is exercised deterministically; a read-out in the
-    middle must flush whatever is held."""
+    with its own seam region between it and the span before).  Spans are held until the round is full (the
+    deterministic default; negative values are the round-4 spelling of it), so the multi-span planner is exercised
+    span count by span count; the positive entries run PSDC_OPT_EAGER (held spans go out when the device is seen
+    idle); a read-out in the middle must flush whatever is held."""
     import torch
     lens = [40 * n + 4, 9 * n, 300 * n, 4 * (n + 288), 57 * n + 8, 120 * n, 33 * n + 12, 5 * n, 64 * n]
     x = make_signal(pkg, sum(lens), seed=900 + n, tone=0.25)
     xd = torch.from_numpy(x).cuda()
     torch.cuda.synchronize()
     g = pkg.PsdCascadeBank(n, 1)
-    g.configure(coalesce=coalesce)
+    g.configure(coalesce=coalesce, eager=coalesce > 0)
     chunks, a = [], 0
     for i, m in enumerate(lens):
         g.process_device(0, xd.data_ptr() + 4 * a, m)
@@ -682,7 +683,7 @@ def test_coalesced_spans_deep(pkg, ora, gpu_required, n, coalesce):
     xd = torch.from_numpy(x).cuda()
     torch.cuda.synchronize()
     g = pkg.PsdCascadeBank(n, 1)
-    g.configure(coalesce=coalesce)
+    g.configure(coalesce=coalesce, eager=coalesce > 0)
     chunks, a = [], 0
     for m in lens:
         g.process_device(0, xd.data_ptr() + 4 * a, m)
@@ -690,6 +691,56 @@ def test_coalesced_spans_deep(pkg, ora, gpu_required, n, coalesce):
         a += m
     check_against_oracle(pkg, ora, g, chunks, n, what=f"coalesce {coalesce}, 26 spans")
     g.close()
+
+
+@pytest.mark.parametrize("n,nch,span_log2,nspans,coalesce", [(1024, 1, 22, 40, None), (1024, 1, 20, 50, 8), (1024, 3, 20, 24, None),
+                                                              (4096, 1, 22, 21, 5), (256, 2, 19, 36, None)])
+def test_same_calls_same_bits(pkg, ora, gpu_required, n, nch, span_log2, nspans, coalesce):
+    """The reference adds segment by segment into one accumulator and is deterministic to the bit (src/psd.rs:228-233).  Here the
+    grouping of the sums follows the rounds, and which device spans share a round is decided by the CALL SEQUENCE alone
+    (include/psdcascade.h Conventions, PSDC_OPT_COALESCE) -- never by how busy the device happens to be: the same >= 20 in-place
+    spans fed twice, once back to back and once with host sleeps injected between the calls (so that the device drains, or does not,
+    at other points), give bit-identical accumulators at every stage, and identical pending samples.  (Through round 4 a held span
+    went out when hipStreamQuery saw the device idle and this test fails there.)  A third handle in PSDC_OPT_EAGER mode -- the old
+    rule, on request -- must agree to rounding (2e-6) and in every counter."""
+    import time
+    import torch
+    m = 1 << span_log2
+    rng = np.random.default_rng(n + nch + nspans)
+    xd = [torch.empty(m * nspans, dtype=torch.float32, device="cuda") for _ in range(nch)]
+    for c in range(nch):
+        pkg.fill_noise_device(xd[c].data_ptr(), m * nspans, seed=0x7654321 + c)
+    torch.cuda.synchronize()
+    pauses = rng.random((nspans, nch)) < 0.35
+
+    def run(sleeps, eager=False):
+        g = pkg.PsdCascadeBank(n, nch)
+        if coalesce is not None:
+            g.configure(coalesce=coalesce)
+        if eager:
+            g.configure(eager=True)
+        for i in range(nspans):
+            for c in range(nch):
+                g.process_device(c, xd[c].data_ptr() + 4 * m * i, m)
+                if sleeps and pauses[i, c]:
+                    time.sleep(0.004)  # a 2^22-sample round is ~10 us of kernel: the device is idle long before the next call
+        out = []
+        for c in range(nch):
+            ns = g.num_stages(c)
+            out.append([(g.stage_info(c, k), g.stage_spectrum(c, k), g.stage_buf(c, k)) for k in range(ns)])
+        g.close()
+        return out
+
+    a, b, e = run(False), run(True), run(True, eager=True)
+    for c in range(nch):
+        assert len(a[c]) == len(b[c]) == len(e[c]) >= 3
+        for k, ((ia, sa, ba), (ib, sb, bb), (ie, se, be)) in enumerate(zip(a[c], b[c], e[c])):
+            assert ia == ib == ie, (c, k)
+            assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)), f"channel {c} stage {k}: spectra differ between two runs of the same calls"
+            assert np.array_equal(ba.view(np.uint32), bb.view(np.uint32)), f"channel {c} stage {k}: pending samples differ"
+            if ia["count"]:
+                assert np.max(np.abs(se.astype(np.float64) - sa) / sa) <= 2e-6, f"channel {c} stage {k}: eager grouping beyond rounding"
+            assert be.shape == ba.shape and (not ba.size or np.max(np.abs(be - ba)) <= 4e-6 * max(1e-3, float(np.max(np.abs(ba)))))
 
 
 def test_full_size_properties(pkg, ora, gpu_required):
@@ -903,8 +954,8 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     xd = [torch.from_numpy(x).cuda() for x in xs]
     torch.cuda.synchronize()
     g = pkg.PsdCascadeBank(n, nch, window=window)
-    g.configure(quantum=int(rng.integers(2, 20)) * n,
-                coalesce=int(rng.choice([1, 4, 8, 16, -2, -4, -8, -16])))  # negative: in-place spans held back unconditionally
+    co = int(rng.choice([1, 4, 8, 16, -2, -4, -8, -16]))  # negative: in-place spans held until the round is full (the default rule);
+    g.configure(quantum=int(rng.integers(2, 20)) * n, coalesce=co, eager=co > 0)  # positive: PSDC_OPT_EAGER, they also go out on an idle device
     refs = [ora.PsdCascade(n, "f64", window=wname) for _ in range(nch)]
     pos = [0] * nch
     detrends = ["none", "midpoint", "span", "mean"]
@@ -1264,7 +1315,7 @@ def test_rectangular_window_single_segment_kernels(pkg, ora, gpu_required, n, de
     d = torch.from_numpy(x).cuda()
     g = pkg.PsdCascadeBank(n, window=pkg.Window.RECTANGULAR)
     g.set_detrend(pkg.Detrend[detrend.upper()])
-    g.configure(coalesce=-4)  # spans are held back and share rounds, as on a busy device
+    g.configure(coalesce=4)  # spans are held back and share rounds
     av = pkg.AvgOpts(*avg) if avg else None
     if av:
         g.set_avg(av)

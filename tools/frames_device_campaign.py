@@ -31,7 +31,7 @@ for seed in range(first, first + count):
         if avg is not None:
             g.set_avg(avg)
         co = int(rng.integers(1, 9))
-        g.configure(coalesce=-co if rng.random() < 0.5 else co)
+        g.configure(coalesce=co, eager=rng.random() < 0.5)
         pos = 0
         while pos < nframes:
             big = rng.random() < 0.7

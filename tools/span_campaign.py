@@ -41,8 +41,8 @@ for seed in range(first, first + count):
     torch.cuda.synchronize()
     try:
         g = pkg.PsdCascadeBank(n)
-        co = int(rng.choice([1, 4, 16, -2, -3, -4, -8, -11, -16]))  # negative: spans are held back even on an idle device
-        g.configure(coalesce=co)
+        co = int(rng.choice([1, 4, 16, -2, -3, -4, -8, -11, -16]))  # negative: spans are held until the round is full; positive: PSDC_OPT_EAGER
+        g.configure(coalesce=co, eager=co > 0)
         g.set_detrend(pkg.Detrend[detrend.upper()])
         if avg:
             g.set_avg(pkg.AvgOpts(*avg))
