@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -184,6 +185,26 @@ def host_fed_rate(pkg, n, device, seconds=2.0):
     return {"value": done / dt / 1e6, "unit": "MS/s",
             "note": "host numpy buffer -> psdc_process (copy to pinned staging split over <= 4 host threads, "
                     "hipMemcpyAsync, kernels); link-bound"}
+
+
+def host_fed_small(n, device, seconds=0.5):
+    """The boundary at the reference's own call granularity (src/source.rs:150-157: 512 samples per Source::get; src/psd.rs:554-559:
+    65536 per call in its `insn` bench), measured from C++ with no Python in the loop: tests/host/smallcall_probe feeds psdc_process
+    on HOST memory in calls of 512 / 4096 / 65536 / 2^22 samples and reports MS/s to the drain and ns per call.  A child process
+    (this one keeps its own GPU context; nothing of the headline is running any more)."""
+    exe = os.path.join(ROOT, "tests", "host", "smallcall_probe")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host"), "smallcall_probe"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": "tests/host/smallcall_probe did not build: " + r.stderr[-300:]}
+    r = subprocess.run([exe, str(n), str(seconds), str(device)], capture_output=True, text=True, timeout=120)
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        return {"error": f"smallcall_probe rc={r.returncode}: {r.stderr[-300:]}"}
+    d = json.loads(line)
+    d["note"] = ("psdc_process(host memory) from C++ in calls of 512 / 4096 / 65536 / 2^22 samples (the reference's Source::get, frame and "
+                 "`insn` granularities): staging copy, upload and the whole cascade; PCIe-inclusive, never `value`")
+    return d
 
 
 def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None, window=None):
@@ -654,6 +675,7 @@ def main():
         if not args.no_cpu_baseline:
             if world == 1 and not frames:
                 out["host_fed"] = host_fed_rate(pkg, n, local_rank)
+                out["host_fed_small"] = host_fed_small(n, local_rank)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, threads=max(1, min(C * world, cores)))
         print(json.dumps(out))

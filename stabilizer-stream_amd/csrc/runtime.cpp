@@ -1072,6 +1072,20 @@ int psdc_set_avg(psdc_handle *h, uint32_t limit, uint32_t count)
 
 int psdc_process(psdc_handle *h, uint32_t channel, const float *x, size_t len)
 {
+    // The reference's callers hand over 512 samples (Source::get for Data::Raw, src/source.rs:150-157) or one frame's worth per call
+    // (src/bin/psd.rs:172-181): a call that only adds to a staging buffer which stays below its quantum is a bounds check and a
+    // memcpy -- no HIP call at all, not even the device query of ON_DEVICE (tests/host/smallcall_probe.cpp measures the boundary
+    // at these sizes).  Everything else takes the general path below.
+    static const bool no_fast = getenv("PSDC_NO_FASTPATH") != nullptr; // (A/B aid: every call through the general path)
+    if (h && channel < h->n_channels && x && len && !no_fast) {
+        Channel &cf_ = h->ch[channel];
+        if (cf_.stage_host[0] && !cf_.st.empty() && cf_.spans.empty() && len < h->quantum - cf_.fill && len < ((size_t)1 << 19)) { // (>= 2 MiB: the copy threads)
+            memcpy(cf_.stage_host[cf_.cur_stage] + cf_.fill, x, sizeof(float) * len);
+            cf_.fill += len;
+            h->idle = false;
+            return PSDC_OK;
+        }
+    }
     int rc = check_channel(h, channel);
     if (rc)
         return rc;
