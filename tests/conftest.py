@@ -67,7 +67,7 @@ def gpu_required():
 #       (err / tol against max_k e32_k / tol_k).  The comparison is with the reference's worst bin, not with the same
 #       bin: on signals that need the widening (a step of 1e5 sigma inside a segment, a tone 60 dB above the noise) the
 #       errors of an f32 FFT are outliers at bins its radix structure picks, and the GPU's (4, 16, ..., 16) passes pick
-#       others than a radix-2 does -- tools/dbg_excess.py: equal rms, different bins.  So no bin passes on the widening
+#       others than a radix-2 does (measured on the level-steps signal: equal rms, different bins).  So no bin passes on the widening
 #       unless the reference's own arithmetic needs as much of it somewhere in the same spectrum.
 # The terminal summary names the test and bin with the largest excess and the one closest to cap (b); assertions
 # that are widened WITHOUT a ref_f32 are counted and their worst non-widened bin is named too.

@@ -798,7 +798,7 @@ def test_config3_full_size(pkg, ora, gpu_required):
     n, batches = 4096, 22
     nframes = -(-(1 << 24) // (8 * batches))
     per = nframes * 8 * batches
-    lsb = np.float32(4.096 * 2.5 / 32768.0)
+    lsb = np.float32(4.096) * np.float32(2.5) / np.float32(32768)  # f32 arithmetic, as src/de/data.rs:31 (the f64 quotient rounds one ulp lower)
     words = np.stack([np.clip(np.round(pkg.noise_host(per, 0x7654321 + c).astype(np.float64) * 4096), -32768, 32767)
                       .astype(np.int16) for c in range(4)])
     wire = words.copy()
