@@ -252,8 +252,11 @@ int psdc_process_frames(psdc_handle *h, const uint8_t *frames, size_t frame_size
  *   the seam / tail of a span is read by the FIRST launch of the next round, i.e. possibly after this call AND the next one
  *   have returned.  Elsewhere (other sizes and windows, pieces shorter than 4 (n + 288) samples per trace) a decode kernel
  *   writes the four traces into the stage-0 stream buffers.
- * Lifetime: d_frames must stay valid and UNMODIFIED until psdc_sync(), any read-out, or an event from psdc_record_consumed
- *   has completed.  Ordering: the handle works on its own non-blocking streams and there is no implicit null-stream order:
+ * Lifetime: d_frames must stay valid and its PAYLOAD bytes unmodified until psdc_sync(), any read-out, or an event from
+ *   psdc_record_consumed has completed.  The 8 header bytes of each frame are read by this call's verdict launch only, which
+ *   has completed when the call returns: a ring that re-stamps `seq` words (or a replay that moves them on, bench.py
+ *   FrameReplay) may rewrite headers as soon as the call is back
+ *   (tests/test_gpu_frames_inplace.py::test_headers_may_change_once_the_call_has_returned).  Ordering: the handle works on its own non-blocking streams and there is no implicit null-stream order:
  *   the producer of d_frames must have COMPLETED before the call (or use psdc_process_device_after's event for f32 spans).
  * Alignment: any base address is accepted.  The in-place path needs d_frames to be a multiple of 8 bytes (frame_size =
  *   8 + 64 batches keeps every later frame aligned); other bases take the byte-wise decode kernel -- same results, slower. */

@@ -53,6 +53,17 @@ int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, 
     if (frame_size < 8) // &input[..HEADER_SIZE] panics (src/de/frame.rs:50)
         return fail(h, PSDC_ERR_FRAME_SIZE, "frame shorter than its header");
     size_t good = 0;
+    // *n_ok is the number of frames ingested at EVERY exit, device errors in mid-call included; a piece's frames enter `good` and
+    // Loss only once the piece is enqueued (its samples are in the streams), never before
+    struct StoreOk {
+        size_t *p;
+        const size_t &v;
+        ~StoreOk()
+        {
+            if (p)
+                *p = v;
+        }
+    } store_ok{n_ok, good};
     int bad = PSDC_OK;
     const size_t payload = frame_size - 8;
     size_t f0 = 0;
@@ -68,14 +79,12 @@ int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, 
             bad = PSDC_ERR_FRAME_FORMAT;
             break;
         }
-        if ((int)h->n_channels < wf->ntr) {
-            if (n_ok)
-                *n_ok = good;
+        if ((int)h->n_channels < wf->ntr)
             return fail(h, PSDC_ERR_ARG, "the frames carry more traces than the handle has channels");
-        }
         const int ntr = wf->ntr;
         const int batches = (int)(payload / wf->batch_bytes);
         bool run_end = false; // a frame of another (valid) format: the next run starts there
+        psdc_loss trial = h->loss; // Loss::update over the piece being scanned: committed to the handle with the piece
         // host: validate headers (src/de/frame.rs:25-37, src/de/data.rs:22-25, 91-93, 149-150, 173-174) and keep the loss
         // counters (Loss::update, src/loss.rs:11-26), piece by piece inside the upload loop below so
         // that the scan of one piece runs while the piece before it is on the link
@@ -99,16 +108,17 @@ int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, 
                     return i;
                 }
                 const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
-                h->loss.received += f[3];
-                if (h->loss.have_seq)
-                    h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
-                h->loss.next_seq = seq + f[3];                              // wrapping_add
-                h->loss.have_seq = 1;
+                trial.received += f[3];
+                if (trial.have_seq)
+                    trial.dropped += (uint32_t)(seq - trial.next_seq); // wrapping_sub
+                trial.next_seq = seq + f[3];                            // wrapping_add
+                trial.have_seq = 1;
             }
             return cnt;
         };
         if (batches == 0) {
             const size_t cnt = scan(f0, n_frames - f0); // header-only frames carry no samples
+            h->loss = trial;
             good += cnt;
             f0 += cnt;
             continue;
@@ -149,8 +159,8 @@ int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, 
         }
         h->idle = false;
         while (f0 < n_frames && bad == PSDC_OK && !run_end) {
+            trial = h->loss;
             const size_t cnt = scan(f0, std::min(piece_frames, n_frames - f0));
-            good += cnt;
             if (cnt == 0)
                 break;
             const size_t bytes = cnt * frame_size;
@@ -203,14 +213,14 @@ int ingest_frames_host(psdc_handle *h, bool adcdac_only, const uint8_t *frames, 
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
                 h->ch[ci].submitted = true;
             }
+            h->loss = trial; // the piece is in the streams: its frames count from here on
+            good += cnt;
             rc = advance(h);
             if (rc)
                 return rc;
             f0 += cnt;
         }
     }
-    if (n_ok)
-        *n_ok = good;
     if (bad != PSDC_OK)
         return fail(h, bad,
                     bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
@@ -317,15 +327,28 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                 return rc;
         }
     }
-    if (good) { // Loss::update over the accepted frames (src/loss.rs:11-26)
-        h->loss.received += res[1];
+    // Loss::update over the accepted frames (src/loss.rs:11-26): summed on the device above, committed to the handle below once
+    // every piece is enqueued -- a device error in mid-call leaves Loss as it was and reports the frames enqueued so far in *n_ok
+    psdc_loss trial = h->loss;
+    if (good) {
+        trial.received += res[1];
         const uint32_t seq0 = (uint32_t)res[3], next = (uint32_t)(res[3] >> 32);
-        if (h->loss.have_seq)
-            h->loss.dropped += (uint32_t)(seq0 - h->loss.next_seq); // wrapping_sub
-        h->loss.dropped += res[2];
-        h->loss.next_seq = next;
-        h->loss.have_seq = 1;
+        if (trial.have_seq)
+            trial.dropped += (uint32_t)(seq0 - trial.next_seq); // wrapping_sub
+        trial.dropped += res[2];
+        trial.next_seq = next;
+        trial.have_seq = 1;
     }
+    size_t enq = 0; // frames whose samples are in the streams
+    struct StoreOk {
+        size_t *p;
+        const size_t &v;
+        ~StoreOk()
+        {
+            if (p)
+                *p = v;
+        }
+    } store_ok{n_ok, enq};
     if (good && batches > 0) {
         h->idle = false;
         const size_t per_frame = (size_t)batches * 8; // samples per trace and frame
@@ -381,6 +404,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                     if (c.spans.size() > 1)
                         c.coalesced_seen = true;
                 }
+                enq += cnt; // (registered: the spans are part of the streams now)
                 // held until PSDC_OPT_COALESCE calls share the round (an eager handle: until the device is seen idle)
                 if (h->ch[0].spans.size() >= h->coalesce || device_idle(h)) {
                     rc = advance(h);
@@ -420,13 +444,14 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                 h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
                 h->ch[ci].submitted = true;
             }
+            enq += cnt;
             rc = advance(h);
             if (rc)
                 return rc;
         }
     }
-    if (n_ok)
-        *n_ok = good;
+    enq = good; // (batches == 0: header-only frames carry no samples and count all the same)
+    h->loss = trial;
     if (bad != PSDC_OK)
         return fail(h, bad,
                     bad == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
@@ -480,9 +505,16 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
     const size_t payload = frame_size - 8;
     size_t good = 0, f0 = 0;
     int bad = PSDC_OK;
+    struct StoreOk { // *n_ok = the frames ingested, at every exit (device errors in mid-call included)
+        size_t *p;
+        const size_t &v;
+        ~StoreOk()
+        {
+            if (p)
+                *p = v;
+        }
+    } store_ok{n_ok, good};
     auto done = [&](int code) {
-        if (n_ok)
-            *n_ok = good;
         return code == PSDC_OK ? PSDC_OK
                                : fail(h, code,
                                       code == PSDC_ERR_FRAME_HEADER   ? "Invalid frame header"
@@ -496,11 +528,8 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
         const WireFmt *wf = wire_fmt(first[2]);
         if (!wf)
             return done(PSDC_ERR_FRAME_FORMAT);
-        if ((int)h->n_channels < wf->ntr) {
-            if (n_ok)
-                *n_ok = good;
+        if ((int)h->n_channels < wf->ntr)
             return fail(h, PSDC_ERR_ARG, "the frames carry more traces than the handle has channels");
-        }
         if (wf->id == 1) { // a run of AdcDac frames: its own entry point checks them (and counts their Loss) on the device
             size_t run = 1;
             while (f0 + run < n_frames && hdr[8 * (f0 + run)] == 0x7b && hdr[8 * (f0 + run) + 1] == 0x05 && hdr[8 * (f0 + run) + 2] == 1)
@@ -508,11 +537,8 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
             size_t ok = 0;
             rc = psdc_process_adcdac_frames_device(h, d_frames + f0 * frame_size, frame_size, run, &ok);
             good += ok;
-            if (rc) {
-                if (n_ok)
-                    *n_ok = good;
+            if (rc)
                 return rc;
-            }
             f0 += run;
             continue;
         }
@@ -533,6 +559,7 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
         while (f0 < n_frames && bad == PSDC_OK && !run_end) {
             size_t cnt = 0;
             const size_t lim = std::min(piece_frames, n_frames - f0);
+            psdc_loss trial = h->loss; // committed with the piece, once it is enqueued
             for (; cnt < lim; ++cnt) { // Header::parse + the payload's size checks + Loss::update, as ingest_frames_host's scan
                 const uint8_t *f = hdr.data() + 8 * (f0 + cnt);
                 if (f[0] != 0x7b || f[1] != 0x05) {
@@ -551,16 +578,18 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
                     break;
                 }
                 const uint32_t seq = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
-                h->loss.received += f[3];
-                if (h->loss.have_seq)
-                    h->loss.dropped += (uint32_t)(seq - h->loss.next_seq); // wrapping_sub
-                h->loss.next_seq = seq + f[3];                              // wrapping_add
-                h->loss.have_seq = 1;
+                trial.received += f[3];
+                if (trial.have_seq)
+                    trial.dropped += (uint32_t)(seq - trial.next_seq); // wrapping_sub
+                trial.next_seq = seq + f[3];                            // wrapping_add
+                trial.have_seq = 1;
             }
-            good += cnt;
             if (cnt == 0)
                 break;
-            if (batches > 0) {
+            if (batches == 0) { // header-only frames carry no samples
+                h->loss = trial;
+                good += cnt;
+            } else {
                 const size_t per_ch = cnt * (size_t)batches;
                 float *dst[4] = {nullptr, nullptr, nullptr, nullptr};
                 for (int ci = 0; ci < ntr; ++ci) {
@@ -583,6 +612,8 @@ int psdc_process_frames_device(psdc_handle *h, const uint8_t *d_frames, size_t f
                     h->ch[ci].st[0].buf.end = h->ch[ci].st[0].total;
                     h->ch[ci].submitted = true;
                 }
+                h->loss = trial;
+                good += cnt;
                 rc = advance(h);
                 if (rc)
                     return rc;

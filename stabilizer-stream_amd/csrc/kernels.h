@@ -184,7 +184,7 @@ int bluestein_size(int n);
 hipError_t launch_welch(int n, const WelchBatch &b, const float *win, const cf *tw, const cf *chirp, const cf *bhat, hipStream_t s);
 // powers of two above what an LDS frame holds (bigfft.hip: 32768 ... BIGFFT_MAX_N): the same jobs through a four-step transform
 // n = n/256 x 256 whose one intermediate frame lives in `scratch` -- every job of the batch shares the launches of a chunk of as many
-// segment pairs as fit (BIGFFT_SCRATCH_ELEMS: 960 pairs at n = 32768, 224 at 131072; chunk_limit > 0 caps it: a test hook) --,
+// segment pairs as fit (BIGFFT_SCRATCH_ELEMS: 976 pairs at n = 32768, 480 at 65536, 224 at 131072; chunk_limit > 0 caps it: a test hook) --,
 // tw[j] = W_n^j; ONE partial row per job (welch_segments_per_tile is "all of them" at these sizes)
 constexpr int BIGFFT_MAX_N = 131072;
 constexpr size_t BIGFFT_SCRATCH_ELEMS = (size_t)2 << 24; // 256 MiB of complex f32

@@ -515,8 +515,13 @@ int psdc_pack_pad(const void *rec, size_t len, void *out, size_t cap, uint32_t n
     else if (!pack_check(rec, len, 0))
         return PSDC_ERR_ARG;
     const size_t own = psdc_readout_bytes(hd->n, hd->n_channels), need = psdc_readout_bytes(hd->n, n_channels);
-    if (!out || out == rec || n_channels < hd->n_channels || need == 0 || cap < need)
+    if (!out || n_channels < hd->n_channels || need == 0 || cap < need)
         return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_pad: fewer channels than the record holds, or buffer too small (psdc_readout_bytes)");
+    {   // [out, out + need) must not touch [rec, rec + len): the copy below is a memcpy and the header rewrite would corrupt the source
+        const uintptr_t o0 = reinterpret_cast<uintptr_t>(out), r0 = reinterpret_cast<uintptr_t>(rec);
+        if (o0 < r0 + len && r0 < o0 + need)
+            return fail(nullptr, PSDC_ERR_ARG, "psdc_pack_pad: out overlaps rec");
+    }
     memcpy(out, rec, own);
     memset(static_cast<char *>(out) + own, 0, need - own); // empty channels: no stages
     PackHeader nh = *hd;
@@ -557,7 +562,7 @@ int psdc_unpack_stitch(const void *buf, size_t len, uint32_t channel, int keep_o
     uint32_t counts[MAX_STAGES], avgs[MAX_STAGES];
     uint64_t counts64[MAX_STAGES], pend[MAX_STAGES];
     std::vector<float> spectra;
-    try { // (nothing unwinds across the ABI; ns <= 16 and bins <= 8193 here, so this is 512 KiB at most)
+    try { // (nothing unwinds across the ABI; ns <= 16 and bins <= PACK_MAX_N / 2 + 1 = 65537 here, so this is ~4 MiB at most)
         spectra.resize((size_t)ns * bins);
     } catch (const std::bad_alloc &) {
         return fail(nullptr, PSDC_ERR_NOMEM, "psdc_unpack_stitch: out of memory");

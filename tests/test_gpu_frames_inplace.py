@@ -110,6 +110,31 @@ def test_frames_in_place_errors(pkg, ora, gpu_required):
         g.close()
 
 
+def test_headers_may_change_once_the_call_has_returned(pkg, ora, gpu_required):
+    """include/psdcascade.h, psdc_process_adcdac_frames_device, Lifetime: the verdict launch is the only reader of the 8 header
+    bytes and has completed when the call returns -- the payload is read later (held spans share rounds; the tail of a span is
+    read by the next round's first launch).  Every call's headers are overwritten with garbage right after the call returns,
+    while its spans are still held: Loss and every spectrum must be what the untouched stream gives."""
+    import torch
+    n, batches, nframes = 1024, 22, 4000
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=77)
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    hdr = d.view(nframes, fs)[:, :8]
+    torch.cuda.synchronize()
+    g = pkg.PsdCascadeBank(n, 4)
+    g.configure(coalesce=4)
+    cuts = [0, 700, 1500, 2100, 3000, 3600, nframes]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert g.process_adcdac_frames_device(d.data_ptr() + a * fs, fs, b - a) == b - a
+        hdr[a:b] = 0xEE  # (torch's stream; the library's streams never read these bytes again)
+        torch.cuda.synchronize()
+    g.sync()
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, channel=c, what=f"headers rewritten, trace {c}")
+    g.close()
+
+
 @pytest.mark.timeout(600)
 def test_config3_frames_in_place_full_size(pkg, ora, gpu_required):
     """BASELINE config 3 with the frames resident in HBM, at full size (2^24 samples per trace, four calls): pure 1e-5
