@@ -88,6 +88,10 @@ extern "C" {
                              * bit-reproducible.  Held spans are caller memory the library has not read yet: the rule of
                              * psdc_process_device (unmodified until sync / read-out / consumed event) covers them.
                              * (-k is accepted and means k: through ABI 3's first builds it asked for exactly this hold.) */
+#define PSDC_OPT_MERGE 6 /* 1 (default): a device span that starts where the last HELD span of its channel ends (d_x == previous d_x +
+                          * previous len: a ring or capture buffer handed over piece by piece) extends that span instead of becoming
+                          * one of its own -- no seam between them, whatever the call size; a channel holds back at most 2^29 samples.
+                          * 0: every call is a span of its own (tests of the multi-span planner). */
 #define PSDC_OPT_EAGER 5 /* 1: a held span also goes out as soon as the device is seen idle (hipStreamQuery) -- the first span of a
                           * burst starts at once instead of waiting for its round to fill, at the price of a round composition
                           * that follows host timing: repeated runs then agree to rounding (<= 2e-6), not to the bit.  Default 0. */

@@ -33,7 +33,7 @@ U32_MAX = 0xFFFFFFFF
 PSDC_OK = 0
 ERR_ARG, ERR_DEVICE, ERR_NOMEM, ERR_UNIMPLEMENTED = -1, -2, -3, -4
 ERR_FRAME_HEADER, ERR_FRAME_FORMAT, ERR_FRAME_SIZE, ERR_CAPACITY = -5, -6, -7, -8
-OPT_QUANTUM, OPT_PROFILE, OPT_COALESCE, OPT_MIN_PAIRS, OPT_EAGER = 1, 2, 3, 4, 5
+OPT_QUANTUM, OPT_PROFILE, OPT_COALESCE, OPT_MIN_PAIRS, OPT_EAGER, OPT_MERGE = 1, 2, 3, 4, 5, 6
 
 
 class PsdError(RuntimeError):
@@ -396,7 +396,9 @@ class PsdCascadeBank:
     def reset(self):
         self._ck(self._L.psdc_reset(self._h))
 
-    def configure(self, quantum=None, profile=None, coalesce=None, min_pairs=None, eager=None):
+    def configure(self, quantum=None, profile=None, coalesce=None, min_pairs=None, eager=None, merge=None):
+        if merge is not None:
+            self._ck(self._L.psdc_configure(self._h, OPT_MERGE, int(bool(merge))))
         if eager is not None:
             self._ck(self._L.psdc_configure(self._h, OPT_EAGER, int(bool(eager))))
         if min_pairs is not None:

@@ -362,13 +362,43 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
             const size_t cnt = std::min(piece_frames, good - f0);
             const size_t per_ch = cnt * per_frame;
             const uint8_t *piece = d_frames + f0 * frame_size;
+            // frames that CONTINUE the run the four traces hold back (a capture ring handed over piece by piece) extend those spans:
+            // no seam, whatever the call size (PSDC_OPT_MERGE, as psdc_process_device)
+            if (in_place_ok && h->merge) {
+                bool can = true;
+                for (int ci = 0; ci < 4 && can; ++ci) {
+                    const Channel &c = h->ch[ci];
+                    can = c.has_span() && c.fill == 0 && !c.submitted && c.spans.back().framed() && c.spans.back().fch == ci &&
+                          c.spans.back().fs.frames + c.spans.back().fs.bytes == piece && c.spans.back().fs.frame_size == (unsigned)frame_size &&
+                          c.spans.back().fs.batches == (unsigned)batches && c.spans.back().fs.frames == h->ch[0].spans.back().fs.frames &&
+                          c.spans.back().len + per_ch <= (size_t)FSPAN_MAX_SAMPLES && held_samples(c) + per_ch <= HOLD_MAX_SAMPLES;
+                }
+                if (can) {
+                    for (int ci = 0; ci < 4; ++ci) {
+                        Channel &c = h->ch[ci];
+                        DeviceSpan &last = c.spans.back();
+                        last.fs.bytes += (unsigned long long)cnt * frame_size;
+                        last.len += per_ch;
+                        c.st[0].total += per_ch;
+                        c.span_max = std::max(c.span_max, last.len);
+                    }
+                    h->idle = false;
+                    enq += cnt;
+                    if (device_idle(h)) {
+                        rc = advance(h);
+                        if (rc)
+                            return rc;
+                    }
+                    continue;
+                }
+            }
             if (in_place_ok && per_ch >= (size_t)4 * (h->n + HBF_HALO)) {
                 // The four traces are read IN PLACE, as wire words, by the stage-0 loads of the fused kernel: a zero-copy span
                 // per trace, exactly like psdc_process_device's -- held back so that calls share rounds (the same rule: runtime.cpp coalesce_limit).
                 bool flush = false;
                 for (int ci = 0; ci < 4; ++ci) {
                     Channel &c = h->ch[ci];
-                    flush = flush || c.submitted || c.fill > 0 || c.spans.size() >= h->coalesce;
+                    flush = flush || c.submitted || c.fill > 0 || c.spans.size() >= h->coalesce || holds_short_span(h, c);
                 }
                 bool any_span = false;
                 for (int ci = 0; ci < 4; ++ci)

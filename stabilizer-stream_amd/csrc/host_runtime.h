@@ -29,6 +29,9 @@ using namespace psdk;
 
 constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the spectra slab
 constexpr int MAX_COALESCE = 16; // zero-copy spans of one channel in one round
+// ... and samples a channel holds back at most: what eight 2^26-sample spans make -- the round size the stream buffers of the deeper
+// stages are sized for; a span merged from contiguous calls stops growing here
+constexpr size_t HOLD_MAX_SAMPLES = (size_t)1 << 29;
 static_assert(MAX_COALESCE <= MAX_FSPANS, "a launch's frame-span table holds every span of a round");
 
 extern thread_local std::string g_last_error;
@@ -160,6 +163,7 @@ struct psdc_handle {
     bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or MAX_COALESCE for one channel fed in short spans (coalesce_limit)
     uint32_t stage_limit = psdrt::MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
+    bool merge = true;  // PSDC_OPT_MERGE: a device span that continues the last held one in memory extends it
     bool eager = false; // PSDC_OPT_EAGER: a held span goes out as soon as the device is seen idle (round composition then follows host timing)
     bool profile = false;
     std::vector<psdrt::ProfEvents> prof_pending;
@@ -230,6 +234,10 @@ int ensure_partial(psdc_handle *h, size_t floats);
 int collect_profile(psdc_handle *h);
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len = 0);
 bool device_idle(psdc_handle *h);
+size_t held_samples(const Channel &c);
+int settle_short_span(psdc_handle *h, Channel &c);
+bool holds_short_span(const psdc_handle *h, const Channel &c);
+bool round_full(const psdc_handle *h, const Channel &c);
 int submit_host(psdc_handle *h, Channel &c);
 int ensure_staging(psdc_handle *h, Channel &c);
 int free_staging(psdc_handle *h, Channel &c);

@@ -93,6 +93,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // the new span in front of the in-place side
     const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * half : 0);
     *did_work = false;
+    for (Channel &c : h->ch) { // a held span that never grew long enough to be read in place becomes a copy (runtime.cpp)
+        int rc = settle_short_span(h, c);
+        if (rc)
+            return rc;
+    }
     {
         int rc = wait_uploads(h);
         if (rc)
@@ -273,7 +278,8 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             const size_t need = (size_t)(t_next - kf_after(w.c, w.k + 1));
             size_t grow_to = 0;
             if (c.span_max) {
-                const uint64_t round_max = (uint64_t)c.span_max * (c.coalesced_seen ? coalesce_limit(h, c) : 1);
+                const uint64_t round_max = std::min<uint64_t>((uint64_t)c.span_max * (c.coalesced_seen ? coalesce_limit(h, c) : 1),
+                                                              std::max<uint64_t>(c.span_max, HOLD_MAX_SAMPLES)); // (a channel never holds more)
                 const unsigned sh = 3u * (w.k + 1);
                 grow_to = (size_t)(sh < 64 ? round_max >> sh : 0) + (size_t)4 * (h->n + HBF_HALO) + 64;
             }

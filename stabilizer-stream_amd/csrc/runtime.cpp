@@ -330,6 +330,14 @@ int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
         add_tail(t);
     for (const TailJob &t : extra)
         add_tail(t);
+    // $PSDC_DBG_SKIP_POST (timing only, WRONG results): the epilogue and the seam copies are dropped, not launched -- the upper bound of
+    // what folding post_kernel's work into the fused launch can buy (one launch per round)
+    static const bool skip_post = getenv("PSDC_DBG_SKIP_POST") != nullptr;
+    if (skip_post) {
+        h->pend_red.clear();
+        h->pend_tail.clear();
+        return PSDC_OK;
+    }
     const size_t nr = h->pend_red.size(), nt = tails.size();
     for (size_t ri = 0, ti = 0; ri < nr || ti < nt;) {
         RedBatch rb{};
@@ -472,6 +480,41 @@ uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
         return MAX_COALESCE;
     return h->coalesce;
 }
+
+bool holds_short_span(const psdc_handle *h, const Channel &c)
+{
+    return c.spans.size() == 1 && !c.spans[0].framed() && c.spans[0].len < (size_t)4 * (h->n + HBF_HALO);
+}
+
+// A channel's ONLY held span is still shorter than what the planner reads in place (4 (n + 288) samples): it becomes a copy behind
+// the stream buffer's content, like host-fed samples.  (Only a first span can be that short: psdc_process_device holds a short span
+// only when nothing is held in front of it.)
+int settle_short_span(psdc_handle *h, Channel &c)
+{
+    if (!holds_short_span(h, c))
+        return PSDC_OK;
+    const DeviceSpan sp = c.spans[0];
+    StageState &s0 = c.st[0];
+    c.spans.clear();
+    int rc = ensure_room(h, s0, s0.total);
+    if (rc)
+        return rc;
+    HIPCHK(h, hipMemcpyAsync(s0.buf.p[s0.buf.cur] + (sp.first - s0.buf.base), sp.d_x, sizeof(float) * sp.len, hipMemcpyDeviceToDevice,
+                             h->stream));
+    s0.buf.end = s0.total;
+    c.submitted = true;
+    return PSDC_OK;
+}
+
+size_t held_samples(const Channel &c)
+{
+    size_t t = 0;
+    for (const DeviceSpan &sp : c.spans)
+        t += sp.len;
+    return t;
+}
+// the channel's round goes out now: as many spans as may share one, or as many samples as a round should hold
+bool round_full(const psdc_handle *h, const Channel &c) { return c.spans.size() >= coalesce_limit(h, c) || held_samples(c) >= HOLD_MAX_SAMPLES; }
 
 // eager handles only: nothing of this handle is executing or queued on the device (~0.1 us, tools/probes/stream_query.cpp)
 bool device_idle(psdc_handle *h) { return h->eager && hipStreamQuery(h->stream) == hipSuccess; }
@@ -1023,6 +1066,13 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
         h->coalesce_auto = false;
         return PSDC_OK;
     }
+    case PSDC_OPT_MERGE: {
+        int rc = flush_all(h);
+        if (rc)
+            return rc;
+        h->merge = value != 0;
+        return PSDC_OK;
+    }
     case PSDC_OPT_EAGER: {
         int rc = flush_all(h);
         if (rc)
@@ -1154,14 +1204,31 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     if (producer_event)
         HIPCHK(h, hipStreamWaitEvent(h->stream, static_cast<hipEvent_t>(producer_event), 0));
     Channel &c = h->ch[channel];
+    // A span that CONTINUES the last held one in memory (a ring buffer being filled, a capture buffer handed over piece by piece)
+    // simply extends it: no seam, no job of its own, whatever its length -- a stream fed in 2^16-sample calls from one buffer runs
+    // like one fed in 2^26-sample calls (tests/host/devcall_probe.cpp).  Contiguity is a property of the call sequence, so the
+    // grouping stays deterministic.  PSDC_OPT_MERGE = 0 turns it off (tests of the multi-span planner).
+    if (h->merge && c.has_span() && c.fill == 0 && !c.submitted) {
+        DeviceSpan &last = c.spans.back();
+        if (!last.framed() && last.d_x + last.len == d_x && held_samples(c) + len <= HOLD_MAX_SAMPLES) {
+            last.len += len;
+            c.st[0].total += len;
+            c.span_max = std::max(c.span_max, last.len);
+            h->idle = false;
+            if (h->n_channels == 1 && (round_full(h, c) || device_idle(h)))
+                return advance(h);
+            return PSDC_OK;
+        }
+    }
     const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
-    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them (coalesce_limit: the rule is a function of the calls
-    // alone).  An EAGER handle also sends them out when it sees the device idle (the stream is asked at most ONCE per call; a
-    // "busy" answer stands for the rest of the call).
+    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them and at most HOLD_MAX_SAMPLES in all (round_full: the rule
+    // is a function of the calls alone).  An EAGER handle also sends them out when it sees the device idle (the stream is asked
+    // at most ONCE per call; a "busy" answer stands for the rest of the call).
     bool flush = c.submitted, known_busy = false;
     if (c.has_span()) {
-        if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len))
+        if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len) || held_samples(c) + len > HOLD_MAX_SAMPLES ||
+            holds_short_span(h, c)) // (a short span is held only while it can still grow: this call does not continue it)
             flush = true;
         else if (device_idle(h))
             flush = true;
@@ -1183,6 +1250,16 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     }
     StageState &s0 = c.st[0];
     h->idle = false;
+    if (!in_place && h->merge && !c.has_span() && !c.submitted && c.fill == 0) {
+        // A short span with nothing held in front of it is held all the same: the calls that continue it in memory extend it
+        // (above), and it is read in place once it is long enough; if its round comes first, advance_round copies it
+        // (settle_short_span) -- so a buffer handed over in pieces of a few hundred samples costs a round per ROUND, not per call.
+        c.spans.push_back({d_x, s0.total, len});
+        s0.total += len;
+        if (h->n_channels == 1 && device_idle(h))
+            return advance(h);
+        return PSDC_OK;
+    }
     if (!in_place) {
         // short span: append a copy, like host-fed samples
         rc = ensure_room(h, s0, s0.total + len);
@@ -1201,7 +1278,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
             c.coalesced_seen = true;
     }
     if (h->n_channels == 1) {
-        if (c.has_span() && !c.submitted && c.spans.size() < coalesce_limit(h, c) && (known_busy || !device_idle(h)))
+        if (c.has_span() && !c.submitted && !round_full(h, c) && (known_busy || !device_idle(h)))
             return PSDC_OK; // held: the next span may share this one's round
         return advance(h);
     }

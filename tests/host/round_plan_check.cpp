@@ -192,6 +192,7 @@ void scenario_stress(uint64_t seed)
     const int cov = co[r.u(0, 8)];
     CK(psdc_configure(h, PSDC_OPT_COALESCE, cov));
     CK(psdc_configure(h, PSDC_OPT_EAGER, cov > 0 ? 1 : 0)); // (positive: held spans also go out when the modelled stream is idle)
+    CK(psdc_configure(h, PSDC_OPT_MERGE, r.f() < 0.35 ? 1 : 0)); // (the feeds are slices of one array: merged they are ONE span)
     if (r.f() < 0.5)
         CK(psdc_configure(h, PSDC_OPT_MIN_PAIRS, (int64_t)r.u(0, 40)));
     std::vector<uint64_t> pos((size_t)nch, 0);
@@ -279,6 +280,7 @@ void scenario_spans(uint64_t seed)
         xs.push_back(ident_stream(c, total));
     CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 17)));
     CK(psdc_configure(h, PSDC_OPT_EAGER, r.f() < 0.4 ? 1 : 0)); // (eager: held spans go out when the modelled stream is idle)
+    CK(psdc_configure(h, PSDC_OPT_MERGE, r.f() < 0.3 ? 1 : 0));
     if (r.f() < 0.5)
         CK(psdc_configure(h, PSDC_OPT_MIN_PAIRS, (int64_t)r.u(0, 300)));
     std::vector<uint64_t> pos((size_t)nch, 0);

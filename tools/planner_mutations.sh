@@ -2,7 +2,7 @@
 # tools/planner_mutations.sh -- does tests/host/round_plan_check notice a broken planner?  Four one-line bugs are seeded into a
 # COPY of the host runtime (csrc/planner.cpp, csrc/runtime.cpp) (a tail carried one sample short; the fused jobs' output pointer off by one; a seam four samples
 # short; stream buffers grown one float too small) and the check is rebuilt against each: every one must fail (identity
-# mismatches for the first three, an AddressSanitizer heap-buffer-overflow for the last).  CPU only, ~5 minutes (thirty seeds: the head-of-span seam copy of mutation 3 is exercised by few scenarios).
+# mismatches for the first three, an AddressSanitizer heap-buffer-overflow for the last).  CPU only, ~8 minutes (sixty seeds: the last samples of the head-of-span seam copy of mutation 3 are read by few scenarios -- first caught at seed 41 of the round-5 scenario stream).
 set -u
 root=$(cd "$(dirname "$0")/.." && pwd)
 C=$root/stabilizer-stream_amd/csrc
@@ -23,7 +23,7 @@ for m in 1 2 3 4; do
   sed -i "s#\"../../include/psdcascade.h\"#\"$root/include/psdcascade.h\"#" $T/host_runtime.h
   g++ -O1 -g -std=c++17 -w -fsanitize=address,undefined -fno-sanitize-recover=undefined -I$H/sim -I$T -I$C -I$H $H/round_plan_check.cpp $H/sim/sim_kernels.cpp \
       $T/runtime.cpp $T/planner.cpp $T/frames_ingest.cpp $T/readout.cpp -o $T/chk$m -lpthread || { echo "mutation $m: build failed"; bad=1; continue; }
-  if timeout 900 $T/chk$m 1 30 > $T/out$m.log 2>&1; then echo "mutation $m: NOT DETECTED"; bad=1
+  if timeout 1500 $T/chk$m 1 60 > $T/out$m.log 2>&1; then echo "mutation $m: NOT DETECTED"; bad=1
   else echo "mutation $m: detected ($(grep -c '^FAIL' $T/out$m.log) failures, $(grep -c 'ERROR: AddressSanitizer' $T/out$m.log) ASan report)"; fi
 done
 exit $bad

@@ -42,7 +42,7 @@ for seed in range(first, first + count):
     try:
         g = pkg.PsdCascadeBank(n)
         co = int(rng.choice([1, 4, 16, -2, -3, -4, -8, -11, -16]))  # negative: spans are held until the round is full; positive: PSDC_OPT_EAGER
-        g.configure(coalesce=co, eager=co > 0)
+        g.configure(coalesce=co, eager=co > 0, merge=bool(seed % 4 == 0))
         g.set_detrend(pkg.Detrend[detrend.upper()])
         if avg:
             g.set_avg(pkg.AvgOpts(*avg))
