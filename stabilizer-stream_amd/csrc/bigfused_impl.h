@@ -424,6 +424,14 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
             asm volatile("" : "+s"(tw0p), "+s"(twap), "+s"(winp));
         }
         PSDK_BSTAMP(0); // between pairs
+        f2 yc[VT]; // stage C: N/8 outputs, two per lane; stored further down, see there
+        // -DPSDK_ABL=4 (timing only, WRONG results): no decimator at all -- state, stages A / B / C and their two barriers gone, the
+        // output store kept (round 5: what a decimator taken OUT of the sixteen-wavefront lockstep could give back at N = 16384)
+        if constexpr ((PSDK_ABL & 4) != 0) {
+#pragma unroll
+            for (int r = 0; r < VT; ++r)
+                yc[r] = {up[r][0].x, nl[r][0].y};
+        } else {
         // ---- decimator (at raised priority, as in fused.hip: +3 % at N = 2048 / 4096) ----------
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(PSDK_DEC_PRIO);
@@ -513,7 +521,6 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
         }
         __syncthreads();
         PSDK_BSTAMP(3); // stage B + barrier
-        f2 yc[VT]; // stage C: N/8 outputs, two per lane; stored further down, see there
 #pragma unroll
         for (int r = 0; r < VT; ++r) {
             const int u = tp + THREADS * r;
@@ -524,6 +531,7 @@ __global__ __launch_bounds__(BigGeo<N>::THREADS, BigGeo<N>::WPS) void bigfused_k
 
         if constexpr (VT == 1)
             __builtin_amdgcn_s_setprio(0);
+        } // !(PSDK_ABL & 4)
 
         // ---- detrend parameters (block-wide broadcast / reduction through LDS) -------------
         DetrendParams dp;

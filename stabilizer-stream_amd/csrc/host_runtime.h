@@ -114,9 +114,11 @@ struct psdc_handle {
     // An upload lands in the stage-0 buffer that the round BEFORE the latest one read (ping-pong),
     // whose end region is also the source of that round's tail carry -- which is deferred into the
     // latest round's post launch.  So an upload may overlap the latest round's fused kernel but must
-    // wait for its post launch: ev_post is recorded right behind it.
+    // wait for its post launch: ev_post is recorded behind it -- lazily, when an upload is about to be enqueued (order_upload), so
+    // that device-fed streams record no event at all (a recorded event is a system-scope release behind the launch).
     hipEvent_t ev_post = nullptr;
     bool post_marked = false;
+    bool post_dirty = false; // a post launch has been enqueued since ev_post was last recorded (recorded lazily, by order_upload)
     float *d_win = nullptr;
     psdk::cf *d_tw = nullptr;
     psdk::cf *d_tw0g = nullptr, *d_twag = nullptr; // twiddle tables of the N >= 2048 fused kernels

@@ -14,6 +14,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <chrono>
 
 using namespace psdrt;
 
@@ -38,6 +39,33 @@ struct Work {
     int nspans = 0;
 };
 
+} // namespace
+
+namespace {
+// $PSDC_DBG_HOST_TIMING (debugging aid): where the HOST time of a round goes -- totals printed at exit
+struct HostTiming {
+    bool on = getenv("PSDC_DBG_HOST_TIMING") != nullptr;
+    double round = 0, post = 0, fused = 0, other_launch = 0;
+    unsigned long rounds = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    ~HostTiming()
+    {
+        if (on && rounds)
+            fprintf(stderr, "host timing: %lu rounds, %.2f us a round: post launch %.2f, fused launch %.2f, other launches %.2f, planning %.2f\n",
+                    rounds, 1e6 * round / rounds, 1e6 * post / rounds, 1e6 * fused / rounds, 1e6 * other_launch / rounds,
+                    1e6 * (round - post - fused - other_launch) / rounds);
+    }
+} g_ht;
+struct HtScope {
+    double &acc;
+    double t0;
+    explicit HtScope(double &a) : acc(a), t0(g_ht.on ? HostTiming::now() : 0.0) {}
+    ~HtScope()
+    {
+        if (g_ht.on)
+            acc += HostTiming::now() - t0;
+    }
+};
 } // namespace
 
 namespace psdrt {
@@ -93,6 +121,9 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // the new span in front of the in-place side
     const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * half : 0);
     *did_work = false;
+    HtScope ht_round(g_ht.round);
+    if (g_ht.on)
+        ++g_ht.rounds;
     for (Channel &c : h->ch) { // a held span that never grew long enough to be read in place becomes a copy (runtime.cpp)
         int rc = settle_short_span(h, c);
         if (rc)
@@ -151,12 +182,20 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 seams.push_back(span_copy(h, sp, sp.first, buf + r.off + back, (size_t)std::min<uint64_t>(seam, sp.len)));
             }
         }
+        HtScope ht_post(g_ht.post);
         int rc = launch_deferred(h, seams); // with the last round's epilogue
         if (rc)
             return rc;
         h->fs_pool.clear(); // every job that named a pooled span has been launched; this round's jobs pool theirs afresh
-        HIPCHK(h, hipEventRecord(h->ev_post, h->stream)); // see order_upload
-        h->post_marked = true;
+        // (the event an upload waits for -- order_upload -- is recorded only where uploads happen: hosts that feed from device memory
+        // never pay for it.  $PSDC_DBG_EAGER_EVPOST: record it behind every post launch, as through round 4 -- A/B aid)
+        static const bool eager_evpost = getenv("PSDC_DBG_EAGER_EVPOST") != nullptr;
+        if (eager_evpost) {
+            HIPCHK(h, hipEventRecord(h->ev_post, h->stream));
+            h->post_marked = true;
+        } else {
+            h->post_dirty = true; // the compute stream has work an upload must wait for: order_upload records the event then
+        }
     }
 
     // collect the work of this round from the totals as they stand now
@@ -609,7 +648,10 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         const bool first = (i <= (size_t)MAX_JOBS);
         if ((rc = prof_begin(pe, false)))
             return rc;
-        HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b));
+        {
+            HtScope ht_f(g_ht.fused);
+            HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b));
+        }
         if ((rc = prof_end(pe, first, false)))
             return rc;
     }

@@ -374,6 +374,11 @@ int wait_uploads(psdc_handle *h)
 // before an upload is enqueued: the copy stream waits for the latest round's post launch
 int order_upload(psdc_handle *h)
 {
+    if (h->post_dirty) { // rounds were enqueued since the last upload: the event goes behind everything the compute stream holds
+        HIPCHK(h, hipEventRecord(h->ev_post, h->stream));
+        h->post_marked = true;
+        h->post_dirty = false;
+    }
     if (h->post_marked)
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_post, 0));
     return PSDC_OK;

@@ -5,7 +5,7 @@
 // and "scattered" -- the same pieces in an order in which no call continues the one before it (every call a span of its own, up to
 // PSDC_OPT_COALESCE of them per round).  Prints ONE JSON line with MS/s to the drain (psdc_sync) and ns of host time per call.
 // bench.py runs it after the timed region (`device_fed_calls`).
-//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0]
+//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0] [only log2 size = 0: all]
 #include "psdcascade.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -23,6 +23,7 @@ int main(int argc, char **argv)
     const double secs = argc > 2 ? atof(argv[2]) : 0.4;
     const int device = argc > 3 ? atoi(argv[3]) : 0;
     const int eager = argc > 4 ? atoi(argv[4]) : 0;
+    const int only = argc > 5 ? atoi(argv[5]) : 0;
     const size_t total = (size_t)1 << 26;
     float *d = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, total * sizeof(float)) != hipSuccess) {
@@ -38,6 +39,8 @@ int main(int argc, char **argv)
         printf(", \"%s\": {", scattered ? "scattered" : "contiguous");
         bool first = true;
         for (int lg : {26, 24, 22, 20, 18, 16}) {
+            if (only && lg != only)
+                continue;
             const size_t chunk = (size_t)1 << lg, nchunks = total / chunk;
             // scattered: piece i of a pass is chunk (i * step) mod nchunks, step odd and > 1: a permutation in which no piece follows
             // its predecessor in memory (one chunk: the same span again and again, which does not continue itself either)
