@@ -210,6 +210,25 @@ def host_fed_small(n, device, seconds=0.5):
     return d
 
 
+def device_fed_calls(n, device, seconds=0.3):
+    """psdc_process_device at call sizes 2^26 ... 2^16 from C++ (tests/host/devcall_probe): "contiguous" = consecutive pieces of one
+    buffer (each call continues the last one in memory and extends the held span: PSDC_OPT_MERGE), "scattered" = the same pieces
+    in an order in which no call continues its predecessor (every call a span of its own).  A child process, after the timed region."""
+    exe = os.path.join(ROOT, "tests", "host", "devcall_probe")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host"), "devcall_probe"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": "tests/host/devcall_probe did not build: " + r.stderr[-300:]}
+    r = subprocess.run([exe, str(n), str(seconds), str(device)], capture_output=True, text=True, timeout=180)
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        return {"error": f"devcall_probe rc={r.returncode}: {r.stderr[-300:]}"}
+    d = json.loads(line)
+    d["note"] = ("psdc_process_device from C++, one 2^26-sample device buffer handed over in calls of 2^26 ... 2^16 samples; MS/s to the "
+                 "drain and host ns per call; side leg, never `value`")
+    return d
+
+
 def side_leg_raw(pkg, torch, n, log2_batch, device, seconds, buf=None, window=None):
     """A short untimed-by-`value` leg of the same cascade at another shape: 1 channel raw f32, 2^log2_batch samples
     resident in HBM, passes until `seconds` have gone by.  Returns value + kernel-only roofline like the headline's."""
@@ -680,6 +699,7 @@ def main():
             if world == 1 and not frames:
                 out["host_fed"] = host_fed_rate(pkg, n, local_rank)
                 out["host_fed_small"] = host_fed_small(n, local_rank)
+                out["device_fed_calls"] = device_fed_calls(n, local_rank)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, threads=max(1, min(C * world, cores)))
         print(json.dumps(out))
