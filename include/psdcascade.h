@@ -80,9 +80,9 @@ extern "C" {
 
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
-#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8, and 16 for a single
-                             * channel fed in spans of at most 2^25 samples -- a round costs ~20 us whatever it holds; 1 = every
-                             * span its own round).  A span is HELD until its channel holds that many or a call arrives that
+#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8, and for a single channel
+                             * fed in f32 spans of at most 2^25 samples as many as make a round of ~2^28 samples: 16 ... 64 -- a round
+                             * costs ~20 us whatever it holds; 1 = every span its own round).  A span is HELD until its channel holds that many or a call arrives that
                              * cannot join them (host-fed or short spans, settings changes, every read-out, psdc_flush, psdc_sync,
                              * psdc_record_consumed): which spans share a round depends on the calls alone, so results are
                              * bit-reproducible.  Held spans are caller memory the library has not read yet: the rule of

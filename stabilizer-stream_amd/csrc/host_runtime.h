@@ -28,11 +28,12 @@ namespace psdrt {
 using namespace psdk;
 
 constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the spectra slab
-constexpr int MAX_COALESCE = 16; // zero-copy spans of one channel in one round
+constexpr int MAX_COALESCE = 64; // zero-copy spans of one channel in one round (the automatic depth for one channel fed in short f32 spans)
+constexpr int MAX_COALESCE_OPT = 16; // ... as an explicit PSDC_OPT_COALESCE, and for runs of AdcDac frames: a launch's frame-span table
 // ... and samples a channel holds back at most: what eight 2^26-sample spans make -- the round size the stream buffers of the deeper
 // stages are sized for; a span merged from contiguous calls stops growing here
 constexpr size_t HOLD_MAX_SAMPLES = (size_t)1 << 29;
-static_assert(MAX_COALESCE <= MAX_FSPANS, "a launch's frame-span table holds every span of a round");
+static_assert(MAX_COALESCE_OPT <= MAX_FSPANS, "a launch's frame-span table holds every FRAMED span of a round (frame calls hold at most PSDC_OPT_COALESCE <= 16)");
 
 extern thread_local std::string g_last_error;
 
@@ -162,7 +163,7 @@ struct psdc_handle {
     int frames_cur = 0;
     size_t quantum = (size_t)1 << 22;
     uint32_t coalesce = 8; // zero-copy spans per channel held back while the device is busy (1 = none)
-    bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or MAX_COALESCE for one channel fed in short spans (coalesce_limit)
+    bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or 16 ... MAX_COALESCE for one channel fed in short spans (coalesce_limit)
     uint32_t stage_limit = psdrt::MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
     bool merge = true;  // PSDC_OPT_MERGE: a device span that continues the last held one in memory extends it
@@ -253,7 +254,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
 const char *check_window(uint32_t n, const float *win, float power, float nenbw, size_t overlap, int *kind, WindowConsts *wc);
 
 // pool index -> index in a launch's own table (at most MAX_FSPANS distinct spans per launch: the planner holds a channel
-// to MAX_COALESCE = MAX_FSPANS spans per round, and the four traces of a span share one entry)
+// to MAX_COALESCE_OPT = MAX_FSPANS FRAMED spans per round, and the four traces of a span share one entry)
 struct FspanMap {
     FrameSpan *table;
     int used = 0;

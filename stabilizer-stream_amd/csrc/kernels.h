@@ -12,7 +12,10 @@
 namespace psdk {
 
 #ifndef PSDK_MAX_JOBS
-#define PSDK_MAX_JOBS 128
+// 160: a round of sixty-four scattered f32 spans of one channel (two jobs a span + its deep stages: ~139) is ONE fused and ONE post
+// launch (round 5; 128 split it into two of each: scattered 2^16-sample calls 62 -> 73 GS/s, 2^20 446 -> 483, headline and eight channels
+// unchanged; measured with 192)
+#define PSDK_MAX_JOBS 160
 #endif
 constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
 

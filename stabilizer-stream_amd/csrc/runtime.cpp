@@ -481,8 +481,12 @@ int collect_profile(psdc_handle *h)
 // device at once.
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
 {
-    if (h->coalesce_auto && h->n_channels == 1 && std::max(c.span_max, len) <= ((size_t)1 << 25))
-        return MAX_COALESCE;
+    if (h->coalesce_auto && h->n_channels == 1 && std::max(c.span_max, len) <= ((size_t)1 << 25)) {
+        // rounds of about 2^28 samples: sixteen spans of 2^24 ... 2^25 samples, up to sixty-four shorter ones (round 5: spans that do NOT
+        // continue each other in memory -- those merge -- at 2^22 / 2^20 / 2^18 / 2^16 samples a call: tests/host/devcall_probe "scattered")
+        const size_t m = std::max<size_t>(std::max(c.span_max, len), 1);
+        return (uint32_t)std::min<size_t>(MAX_COALESCE, std::max<size_t>(16, ((size_t)1 << 28) / m));
+    }
     return h->coalesce;
 }
 
@@ -1062,7 +1066,7 @@ int psdc_configure(psdc_handle *h, int option, int64_t value)
         return PSDC_OK;
     case PSDC_OPT_COALESCE: {
         const int64_t k = value < 0 ? -value : value; // (-k: what "hold even on an idle device" was spelled through round 4; the default now)
-        if (k < 1 || k > MAX_COALESCE)
+        if (k < 1 || k > MAX_COALESCE_OPT)
             return fail(h, PSDC_ERR_ARG, "coalesce out of range (1..16)");
         int rc = flush_all(h);
         if (rc)

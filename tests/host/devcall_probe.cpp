@@ -5,7 +5,7 @@
 // and "scattered" -- the same pieces in an order in which no call continues the one before it (every call a span of its own, up to
 // PSDC_OPT_COALESCE of them per round).  Prints ONE JSON line with MS/s to the drain (psdc_sync) and ns of host time per call.
 // bench.py runs it after the timed region (`device_fed_calls`).
-//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0] [only log2 size = 0: all]
+//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0] [only log2 size = 0: all] [PSDC_OPT_COALESCE = 0: the library's own depth]
 #include "psdcascade.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -24,6 +24,7 @@ int main(int argc, char **argv)
     const int device = argc > 3 ? atoi(argv[3]) : 0;
     const int eager = argc > 4 ? atoi(argv[4]) : 0;
     const int only = argc > 5 ? atoi(argv[5]) : 0;
+    const int coalesce = argc > 6 ? atoi(argv[6]) : 0;
     const size_t total = (size_t)1 << 26;
     float *d = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, total * sizeof(float)) != hipSuccess) {
@@ -52,6 +53,8 @@ int main(int argc, char **argv)
             }
             if (eager)
                 psdc_configure(h, PSDC_OPT_EAGER, 1);
+            if (coalesce)
+                psdc_configure(h, PSDC_OPT_COALESCE, coalesce);
             auto piece = [&](size_t i) { return d + (scattered ? (i * step) % nchunks : i) * chunk; };
             for (int w = 0; w < 2; ++w) // first-use costs: stream buffers grown to the round size, clocks
                 for (size_t i = 0; i < nchunks; ++i)
