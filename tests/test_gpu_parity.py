@@ -783,6 +783,47 @@ def test_contiguous_device_calls_merge_into_one_span(pkg, ora, gpu_required, n, 
     many.close()
 
 
+@pytest.mark.parametrize("n,piece_log2,npieces", [(1024, 16, 150), (256, 14, 200), (4096, 17, 70)])
+def test_many_scattered_spans_share_a_round(pkg, ora, gpu_required, n, piece_log2, npieces):
+    """One channel fed in short spans that do NOT continue each other in memory (pieces of one buffer in a permuted order: nothing merges):
+    the library's own coalescing depth makes rounds of about 2^28 samples, i.e. up to SIXTY-FOUR spans a round here (round 5; an explicit
+    PSDC_OPT_COALESCE stays within 1 ... 16) -- each with a seam region of its own, ~130 fused jobs in one launch.  The stream is the pieces
+    in the order they were fed: counters, pending samples and spectra against the oracle, a read-out in the middle, and the same
+    calls twice give the same bits."""
+    import torch
+    m = 1 << piece_log2
+    rng = np.random.default_rng(n + npieces)
+    x = make_signal(pkg, m * npieces, seed=7700 + n, tone=0.2, dc=0.05)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    order = rng.permutation(npieces)
+    for i in range(1, npieces):  # no piece may follow its predecessor in memory
+        if order[i] == order[i - 1] + 1:
+            order[i], order[(i + 1) % npieces] = order[(i + 1) % npieces], order[i]
+    order = [int(v) for v in order]
+    order = [v for i, v in enumerate(order) if i == 0 or v != order[i - 1] + 1]
+
+    def run():
+        g = pkg.PsdCascadeBank(n, 1)
+        g.configure(profile=True)
+        for i, k in enumerate(order):
+            g.process_device(0, xd.data_ptr() + 4 * m * k, m)
+            if i == len(order) // 3:
+                assert g.stage_info(0, 0)["count"] > 0  # (a read-out flushes whatever is held)
+        g.sync()
+        return g
+
+    g, g2 = run(), run()
+    launches = g.profile_read()["launches"]
+    assert launches <= 2 + 3 * (len(order) // 64 + 2), f"{launches} fused launches for {len(order)} spans: the spans did not share rounds"
+    chunks = [x[m * k:m * (k + 1)] for k in order]
+    for k in range(g.num_stages(0)):
+        assert np.array_equal(g.stage_spectrum(0, k).view(np.uint32), g2.stage_spectrum(0, k).view(np.uint32)), k
+    check_against_oracle(pkg, ora, g, chunks, n, what=f"{len(order)} scattered spans of 2^{piece_log2}")
+    g.close()
+    g2.close()
+
+
 def test_full_size_properties(pkg, ora, gpu_required):
     """BASELINE config 2 at its full size (2^26 samples, N=1024): size-independent properties, then the f64
     oracle on the same samples."""
