@@ -70,13 +70,6 @@ struct HtScope {
 
 namespace psdrt {
 
-// One round of the cascade pipeline: every (channel, stage) that has complete
-// segments in its stream buffer is issued, all stages in the SAME launches.
-// The decimator output of this round becomes visible to the next stage in the
-// next round (stage k+1 lags one round behind stage k), so a steady-state round
-// costs two launches whatever the depth: a post launch (the seam copy of this round with the
-// deferred epilogue of the last one) and the fused launch (plus the generic welch / decimator
-// kernels when something does not fit a pair).
 // The fused single-pass kernels read the window from its table and assume nothing about it but a hop of N/2: Window::hann()
 // and every caller-built Window<N> with overlap N/2 (Hamming, Blackman, ... -- src/psd.rs:12-20 has pub fields) run on them;
 // overlap 0 (Window::rectangular(), src/psd.rs:24-32, or a caller's table) runs the same kernels in their SINGLE form -- one
@@ -93,59 +86,105 @@ int fused_window(const psdc_handle *h)
     return 0;
 }
 
-// `all`: issue odd segments of decimated stages too (read-outs); the ingest path
-// leaves them for their partner.  *did_work tells whether anything was issued;
-// read-outs call rounds until idle.
-int advance_round(psdc_handle *h, bool *did_work, bool all)
-{
-    const Geometry &g = h->geo;
-    const int spt = welch_segments_per_tile((int)h->n);
-    const int fmode = fused_supported((int)h->n) ? fused_window(h) : 0;
-    const bool fast_ok = fmode != 0, single = fmode == 2;
-    // overlap 0 at the team-kernel sizes: two disjoint segments per transform (FusedBatch::single == 2) -- jobs and runs then hold
-    // an even number of single-segment "pairs".  $PSDC_NO_DOUBLE: one segment per transform everywhere (A/B aid)
-    static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
-    const bool dbl = single && !no_double && fused_double_supported((int)h->n);
-    const unsigned fstep = single ? 1 : 2;   // segments per fused "pair"
-    // a fused run starting at segment j decimates from sample j hop + N/2 on (half-overlapped pairs: the pair's new samples) -- or,
-    // overlap 0, from j N on: a single-segment step transforms exactly the samples it decimates, and its source pointer sits half
-    // a segment in front of the segment (run_src0)
-    const uint64_t half = (uint64_t)h->n / 2;
-    auto run_new0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop + (single ? 0 : half); };
-    auto run_src0 = [&](uint64_t seg) { return seg * (uint64_t)g.hop - (single ? half : 0); }; // (seg >= 1 in single mode)
+
+} // namespace psdrt
+
+namespace {
+
+struct Region { // seam region of span i >= 1 of a channel
+    size_t off;    // floats from the start of the stream buffer
+    uint64_t base; // absolute index of its first sample (the keep_from point after span i-1)
+};
+struct PlanFused {
+    FusedJob j;
+    size_t work;
+};
+struct PlanSeg {
+    SegJob j;
+    size_t work;
+};
+
+// One round of the cascade pipeline, phase by phase (advance_round runs them in order).  Every (channel, stage) that has complete
+// segments in its stream buffer is issued, all stages in the SAME launches; the decimator output of this round becomes visible to
+// the next stage in the next round (stage k+1 lags one round behind stage k), so a steady-state round costs two launches whatever
+// the depth: a post launch (the seam copies of this round with the deferred epilogue of the last one) and the fused launch (plus
+// the generic welch / decimator kernels when something does not fit a pair).
+struct Round {
+    psdc_handle *h;
+    const Geometry &g;
+    const bool all; // issue odd segments of decimated stages too (read-outs); the ingest path leaves them for their partner
+    const int spt;
+    const int fmode; // 0: no fused kernel for this window, 1: half-overlapped pairs, 2: single segments (fused_window)
+    const bool fast_ok, single;
+    bool dbl;        // overlap 0 at the team-kernel sizes: two disjoint segments per transform (FusedBatch::single == 2) -- jobs and runs
+                     // then hold an even number of single-segment "pairs".  $PSDC_NO_DOUBLE: one segment per transform everywhere (A/B aid)
+    const unsigned fstep; // segments per fused "pair"
+    const uint64_t half;
     // fused runs rebuild their decimator state from the 288 samples before their first new
     // sample (which sits N/2 after the run's first segment start): samples needed in front of it
-    const uint64_t need_pre = HBF_HALO > half ? HBF_HALO - half : 0;
+    const uint64_t need_pre;
     // the seam must complete every segment that starts in the carried tail; on the fast path it
     // is long enough for the tail side to end on a whole segment pair with need_pre samples of
     // the new span in front of the in-place side
-    const uint64_t seam = std::max<uint64_t>((uint64_t)h->n + HBF_HALO, fast_ok ? need_pre + 3 * half : 0);
-    *did_work = false;
-    HtScope ht_round(g_ht.round);
-    if (g_ht.on)
-        ++g_ht.rounds;
-    for (Channel &c : h->ch) { // a held span that never grew long enough to be read in place becomes a copy (runtime.cpp)
-        int rc = settle_short_span(h, c);
-        if (rc)
-            return rc;
-    }
+    const uint64_t seam;
+    const uint64_t teams; // teams (= pairs in flight) per workgroup of the fused kernel
+    size_t fused_jpl = MAX_JOBS; // fused jobs per launch (share_workgroups)
+
+    std::vector<std::vector<Region>> regions; // per channel: the seam regions of its spans
+    std::vector<Work> works;                  // what every (channel, stage) owes this round
+    std::vector<PlanFused> fjobs;
+    std::vector<PlanSeg> sjobs;
+    std::vector<DecJob> djobs;
+    std::vector<RedJob> rjobs;                // one per work: the fold of its partials (the deferred epilogue)
+    uint64_t prof_samples = 0, prof_samples0 = 0;
+    size_t blocks_total = 0;
+
+    Round(psdc_handle *h_, bool all_)
+        : h(h_), g(h_->geo), all(all_), spt(welch_segments_per_tile((int)h_->n)), fmode(fused_supported((int)h_->n) ? fused_window(h_) : 0),
+          fast_ok(fmode != 0), single(fmode == 2), fstep(fmode == 2 ? 1 : 2), half((uint64_t)h_->n / 2),
+          need_pre(HBF_HALO > (uint64_t)h_->n / 2 ? HBF_HALO - (uint64_t)h_->n / 2 : 0),
+          seam(std::max<uint64_t>((uint64_t)h_->n + HBF_HALO, fmode != 0 ? need_pre + 3 * half : 0)),
+          teams((uint64_t)std::max(1, fused_pairs_per_block((int)h_->n, 1))), regions(h_->n_channels)
     {
-        int rc = wait_uploads(h);
-        if (rc)
-            return rc;
+        static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
+        dbl = single && !no_double && fused_double_supported((int)h->n);
+    }
+    // a fused run starting at segment j decimates from sample j hop + N/2 on (half-overlapped pairs: the pair's new samples) -- or,
+    // overlap 0, from j N on: a single-segment step transforms exactly the samples it decimates, and its source pointer sits half
+    // a segment in front of the segment (run_src0)
+    uint64_t run_new0(uint64_t seg) const { return seg * (uint64_t)g.hop + (single ? 0 : half); }
+    uint64_t run_src0(uint64_t seg) const { return seg * (uint64_t)g.hop - (single ? half : 0); } // (seg >= 1 in single mode)
+    // where a stream will start after this round (its tail is carried to the
+    // front of its other buffer; the decimator appends the new samples behind it)
+    uint64_t kf_after(uint32_t ci, uint32_t k) const
+    {
+        StageState t = h->ch[ci].st[k];
+        for (auto &w : works)
+            if (w.c == ci && w.k == k) {
+                t.segs = w.j_new;
+                t.dec = w.p_new;
+            }
+        return keep_from(g, t);
     }
 
+    int place_seams();
+    int collect_work();
+    int size_next_stages();
+    void make_jobs();
+    void share_workgroups();
+    int place_partials();
+    int launch();
+    int book();
+};
+
+int Round::place_seams()
+{
     // zero-copy spans: copy the seam (the part that completes segments begun in
     // the carried tail) behind the tail; the bulk is read in place.  One copy
     // launch for all channels.  A channel may hold several spans (PSDC_OPT_COALESCE): each
     // further span gets a seam REGION of its own in the stream buffer, behind the contiguous
     // part -- the tail the span before it would have carried (read from that span's end) followed
     // by the head of the span -- so that the segments straddling two spans see contiguous memory.
-    struct Region { // seam region of span i >= 1 of a channel
-        size_t off;      // floats from the start of the stream buffer
-        uint64_t base;   // absolute index of its first sample (the keep_from point after span i-1)
-    };
-    std::vector<std::vector<Region>> regions(h->n_channels);
     {
         std::vector<TailJob> seams;
         for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
@@ -197,9 +236,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             h->post_dirty = true; // the compute stream has work an upload must wait for: order_upload records the event then
         }
     }
+    return PSDC_OK;
+}
 
-    // collect the work of this round from the totals as they stand now
-    std::vector<Work> works;
+// the work of this round from the totals as they stand now
+int Round::collect_work()
+{
     for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
         Channel &c = h->ch[ci];
         for (uint32_t k = 0; k < c.st.size(); ++k) {
@@ -279,27 +321,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             works.push_back(w);
         }
     }
-    if (works.empty()) {
-        for (auto &c : h->ch) {
-            if (c.has_span())
-                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
-            c.submitted = false;
-        }
-        return PSDC_OK;
-    }
-    *did_work = true;
+    return PSDC_OK;
+}
 
-    // where every stream will start after this round (its tail is carried to the
-    // front of its other buffer; the decimator appends the new samples behind it)
-    auto kf_after = [&](uint32_t ci, uint32_t k) -> uint64_t {
-        StageState t = h->ch[ci].st[k];
-        for (auto &w : works)
-            if (w.c == ci && w.k == k) {
-                t.segs = w.j_new;
-                t.dec = w.p_new;
-            }
-        return keep_from(g, t);
-    };
+// room for what the decimators of this round will append to the next stages' streams
+int Round::size_next_stages()
+{
     for (auto &w : works) {
         Channel &c = h->ch[w.c];
         const uint64_t t_next = emitted_for(g, w.p_new);
@@ -336,7 +363,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 w.spans[i].src_base = s.buf.base;
             }
     }
+    return PSDC_OK;
+}
 
+void Round::make_jobs()
+{
     // ---- turn the work into kernel jobs ---------------------------------
     // Fast path (fused_kernel / bigfused_kernel): whole segment pairs of a Hann stream with
     // N = 256 ... 16384, any implemented detrend, plain-sum or EWMA averaging, 16-byte aligned.
@@ -345,12 +376,6 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // src/psd.rs:235-238; outputs still inside the drain; unaligned zero-copy spans) -- goes
     // through the generic welch / hbf_dec8 kernels.  Both write the same partial slab and
     // next-stage stream, so the reduce and the bookkeeping do not care which ran.
-    struct PlanFused { FusedJob j; size_t work; };
-    struct PlanSeg { SegJob j; size_t work; };
-    std::vector<PlanFused> fjobs;
-    std::vector<PlanSeg> sjobs;
-    std::vector<DecJob> djobs;
-    uint64_t prof_samples = 0, prof_samples0 = 0;
     for (size_t wi = 0; wi < works.size(); ++wi) {
         Work &w = works[wi];
         Channel &c = h->ch[w.c];
@@ -442,10 +467,12 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         if (w.k == 0)
             prof_samples0 += w.p_new - w.p_old;
     }
+}
 
+void Round::share_workgroups()
+{
     // share the persistent workgroups so that every workgroup walks about the same amount
     // shares are computed per launch batch (MAX_JOBS jobs): every launch fills the GPU by itself
-    size_t blocks_total = 0;
     for (size_t b0 = 0; b0 < sjobs.size(); b0 += MAX_JOBS) {
         const size_t b1 = std::min(sjobs.size(), b0 + (size_t)MAX_JOBS);
         size_t tiles = 0;
@@ -457,7 +484,6 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             blocks_total += (size_t)sjobs[i].j.nblocks;
         }
     }
-    const uint64_t teams = (uint64_t)std::max(1, fused_pairs_per_block((int)h->n, 1));
     // Jobs that read frames in place go first in their launch, the four traces of one span side by side (same span, same
     // offset: the same geometry, hence equal workgroup counts): the kernel deals such a group's workgroups over the XCDs so
     // that the four readers of the same bytes share an L2 (FusedBatch::fg_*).
@@ -480,7 +506,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     // Fused jobs per launch: all MAX_JOBS for a single channel (a round of sixty-four scattered spans is then ONE launch), 128 for
     // several channels -- eight channels x eight spans (208 jobs) measured 4 % SLOWER as one launch of 160 + one of 48 than as 128 + 80
     // (658 vs 685-691 GS/s, kernel-only 0.335 vs 0.352: each launch gets the one run length that fills the GPU for ITS jobs)
-    const size_t fused_jpl = h->n_channels == 1 ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, 128);
+    fused_jpl = h->n_channels == 1 ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, 128);
     for (size_t b0 = 0; b0 < fjobs.size(); b0 += fused_jpl) {
         const size_t b1 = std::min(fjobs.size(), b0 + fused_jpl);
         // One run length R for the whole launch: the smallest R for which the jobs' workgroups
@@ -553,11 +579,15 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         std::stable_partition(fjobs.begin() + (std::ptrdiff_t)b0, fjobs.begin() + (std::ptrdiff_t)b1,
                               [&](const PlanFused &pf) { return small_at((uint64_t)pf.j.npairs, R); });
     }
+}
+
+int Round::place_partials()
+{
     int rc = ensure_partial(h, blocks_total * h->n);
     if (rc)
         return rc;
     // slab: the partials of one work are contiguous (fused first, then generic)
-    std::vector<RedJob> rjobs(works.size());
+    rjobs.assign(works.size(), RedJob{});
     {
         // (the jobs of a work need not be adjacent in fjobs: frame jobs were moved to the front)
         std::vector<size_t> nblk(works.size(), 0), base(works.size(), 0);
@@ -586,12 +616,17 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
             base[ps.work] += (size_t)ps.j.nblocks * h->n;
         }
     }
+    return PSDC_OK;
+}
 
+int Round::launch()
+{
     // ---- launches: fused, generic welch, reduce, generic decimator -------
     // HIP events time the dominant kernel of the round (fused when present).  The fused launches
     // hand their events to hipExtLaunchKernelGGL, which stamps the kernel's own start and stop (what
     // rocprofv3 --kernel-trace reports); events recorded around a launch would include the ~6 us
     // dependent-dispatch gap in front of it.  The generic welch kernel keeps the bracket.
+    int rc = PSDC_OK;
     const bool prof_fused = fast_ok; // the handle's dominant kernel kind, not the round's
     auto prof_begin = [&](ProfEvents &pe, bool record) -> int {
         if (!h->profile)
@@ -697,7 +732,11 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
         }
         HIPCHK(h, launch_dec(db, h->stream));
     }
+    return PSDC_OK;
+}
 
+int Round::book()
+{
     // bookkeeping: counts and stream positions
     std::vector<std::vector<uint64_t>> old_total(h->n_channels);
     for (uint32_t ci = 0; ci < h->n_channels; ++ci)
@@ -760,6 +799,48 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     return PSDC_OK;
 }
 
+} // namespace
+
+namespace psdrt {
+
+// `all`: issue odd segments of decimated stages too (read-outs); the ingest path
+// leaves them for their partner.  *did_work tells whether anything was issued;
+// read-outs call rounds until idle.
+int advance_round(psdc_handle *h, bool *did_work, bool all)
+{
+    *did_work = false;
+    HtScope ht_round(g_ht.round);
+    if (g_ht.on)
+        ++g_ht.rounds;
+    for (Channel &c : h->ch) { // a held span that never grew long enough to be read in place becomes a copy (runtime.cpp)
+        int rc = settle_short_span(h, c);
+        if (rc)
+            return rc;
+    }
+    int rc = wait_uploads(h);
+    if (rc)
+        return rc;
+    Round r(h, all);
+    if ((rc = r.place_seams()) || (rc = r.collect_work()))
+        return rc;
+    if (r.works.empty()) {
+        for (auto &c : h->ch) {
+            if (c.has_span())
+                return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
+            c.submitted = false;
+        }
+        return PSDC_OK;
+    }
+    *did_work = true;
+    if ((rc = r.size_next_stages()))
+        return rc;
+    r.make_jobs();
+    r.share_workgroups();
+    if ((rc = r.place_partials()) || (rc = r.launch()))
+        return rc;
+    return r.book();
+}
+
 // one pipeline round (ingest path)
 int advance(psdc_handle *h)
 {
@@ -786,3 +867,4 @@ int drain(psdc_handle *h)
 }
 
 } // namespace psdrt
+

@@ -49,6 +49,19 @@ def main():
         out[f"{name}/spectra"] = np.stack([c.stage_spectrum(k) for k in range(ns)])
         p, br, _ = c.psd()
         out[f"{name}/psd"] = p
+        # the same cascades in the reference's own f32 arithmetic, two independent restatements (radix-2 and radix-4 Stockham FFT):
+        # the yardsticks of the GPU test's widened comparison (tests/conftest.py EXCESS_K) -- the GPU box needs no oracle for them
+        for tag, fast in (("f32", False), ("f32b", True)):
+            c32 = ora.PsdCascade(n, "f32")
+            if fast:
+                c32.set_fast_fft()
+            c32.set_detrend(detrend)
+            if avg:
+                c32.set_avg(*avg)
+            c32.process(signal(pkg, length, seed, tone, dc))
+            assert c32.num_stages == ns
+            out[f"{name}/spectra_{tag}"] = np.stack([c32.stage_spectrum(k) for k in range(ns)])
+            out[f"{name}/psd_{tag}"] = c32.psd()[0]
     np.savez_compressed(os.path.join(os.path.dirname(__file__), "psd_golden.npz"), **out)
     print("wrote", len(out), "arrays")
 

@@ -27,7 +27,7 @@ def test_cascade_any_n_hann(pkg, ora, gpu_required, n, detrend):
     g.process(0, x[:cut])
     d = torch.from_numpy(x[cut:]).cuda()
     g.process_device(0, d.data_ptr(), total - cut)
-    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, what=f"N={n} {detrend}", justify=False)
+    check_against_oracle(pkg, ora, g, [x], n, detrend=detrend, what=f"N={n} {detrend}", justify=n <= 1200)  # (the f32 DFT by definition too, where it is cheap)
     g.close()
 
 
@@ -67,7 +67,9 @@ def test_single_stage_and_caller_window_any_n(pkg, ora, gpu_required):
     y, yr = s.process(x), ref.process(x)
     assert y.size == yr.size and np.max(np.abs(y - yr)) <= 4e-6 * np.max(np.abs(yr))
     assert s.count() == ref.count() and s.buf().size == ref.pending()
-    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<1000> Hamming")
+    r32 = ora.Psd(n, "f32", window=win.as_tuple())  # the yardstick of the widened comparison: the reference's arithmetic in f32
+    r32.process(x)
+    assert_psd_close(s.spectrum(), ref.spectrum(), "Psd<1000> Hamming", ref_f32=r32.spectrum(), real_bins=(0, n // 2))
     s.close()
 
 

@@ -195,7 +195,7 @@ def test_one_call_longer_than_a_frame_span(pkg, ora, gpu_required):
     for c in (0, 3):
         xc = words[c].astype(np.float32) * lsb
         w = check_against_oracle(pkg, ora, g, [xc], n, channel=c, what=f"70.6 M-sample call, {pkg.ADCDAC_TRACES[c]}",
-                                 pure_min_count=4, justify=False)
+                                 pure_min_count=4)
         print(f"one call of 2^26 + samples per trace, {pkg.ADCDAC_TRACES[c]}: worst relative error {w:.3g}")
     g.close()
 

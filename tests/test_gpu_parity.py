@@ -1039,6 +1039,11 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
     g.configure(quantum=int(rng.integers(2, 20)) * n, coalesce=co, eager=co > 0)  # positive: PSDC_OPT_EAGER, they also go out on an idle device
     g.configure(merge=bool(seed % 3 == 0))  # one seed in three: a device span that continues the held one in memory extends it (PSDC_OPT_MERGE)
     refs = [ora.PsdCascade(n, "f64", window=wname) for _ in range(nch)]
+    # the f32 yardsticks of the stage-0 comparison (conftest EXCESS_K): the reference's own arithmetic, two independent restatements
+    refs32 = [[ora.PsdCascade(n, "f32", window=wname) for _ in range(nch)] for _ in range(2 if n & (n - 1) == 0 else 1)]
+    for r in refs32[1] if len(refs32) > 1 else []:
+        r.set_fast_fft()
+    allrefs = lambda c: [refs[c]] + [rr[c] for rr in refs32]
     pos = [0] * nch
     detrends = ["none", "midpoint", "span", "mean"]
     while min(pos) < total:
@@ -1051,16 +1056,18 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
             if os.environ.get("PSD_STRESS_TRACE"):
                 print(f"set_detrend {d}", flush=True)
             g.set_detrend(pkg.Detrend[d.upper()])
-            for r in refs:
-                r.set_detrend(d)
+            for c_ in range(nch):
+                for r in allrefs(c_):
+                    r.set_detrend(d)
             continue
         if kind < 0.12:
             lim, cnt = int(rng.integers(1, 50)), int(rng.integers(1, 400))
             if os.environ.get("PSD_STRESS_TRACE"):
                 print(f"set_avg limit {lim} count {cnt}", flush=True)
             g.set_avg(pkg.AvgOpts(lim, cnt))
-            for r in refs:
-                r.set_avg(lim, cnt)
+            for c_ in range(nch):
+                for r in allrefs(c_):
+                    r.set_avg(lim, cnt)
             continue
         if kind < 0.2:  # mid-stream read-out of one channel
             cc = int(rng.integers(0, nch))
@@ -1079,7 +1086,8 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
             g.process(c, xs[c][a:b])
         else:
             g.process_device(c, xd[c].data_ptr() + 4 * a, m)
-        refs[c].process(xs[c][a:b])
+        for r in allrefs(c):
+            r.process(xs[c][a:b])
         pos[c] = b
     for c in range(nch):
         ns = g.num_stages(c)
@@ -1090,7 +1098,8 @@ def test_randomized_feed_stress(pkg, ora, gpu_required, n, seed):
             gb, rb = g.stage_buf(c, k), refs[c].stage_buf(k)
             if info["count"]:
                 if k == 0:  # the input stream itself: every implementation reads the same f32 samples
-                    assert_psd_close(g.stage_spectrum(c, k), refs[c].stage_spectrum(k), f"ch {c} stage {k}")
+                    assert_psd_close(g.stage_spectrum(c, k), refs[c].stage_spectrum(k), f"ch {c} stage {k}",
+                                     ref_f32=[rr[c].stage_spectrum(k) for rr in refs32], real_bins=(0, n // 2))
                 else:  # f32 stream between stages: one-sample detrend anchors carry its rounding
                     assert_psd_close_anchored(g.stage_spectrum(c, k), refs[c].stage_spectrum(k), n, info["count"],
                                               float(np.max(np.abs(rb))), f"ch {c} stage {k}")
@@ -1462,7 +1471,7 @@ def test_n16384_deep_single_pass_vs_oracle(pkg, ora, gpu_required):
     half = total // 2 + 8 * 1031  # two uneven in-place spans
     g.process_device(0, d.data_ptr(), half)
     g.process_device(0, d.data_ptr() + 4 * half, total - half)
-    w = check_against_oracle(pkg, ora, g, [x], n, what="N=16384, 2^27 samples", pure_min_count=4, justify=False)
+    w = check_against_oracle(pkg, ora, g, [x], n, what="N=16384, 2^27 samples", pure_min_count=4)
     counts = [g.stage_info(0, k)["count"] for k in range(g.num_stages(0))]
     assert counts[:5] == [16383, 2046, 254, 30, 2] == [s for _, s, _ in pkg.plan_counts(n, total)][:5]
     print(f"N=16384 x 2^27 samples vs the f64 oracle: stages {counts}, worst relative error {w:.3g}")
@@ -1485,6 +1494,8 @@ def test_non_finite_samples_propagate_like_the_reference(pkg, ora, gpu_required,
     g.process_device(0, d.data_ptr(), total)
     ref = ora.PsdCascade(n, "f64")
     ref.process(x)
+    r32 = ora.PsdCascade(n, "f32")  # (the yardstick of the widened comparison: the reference's own f32 arithmetic)
+    r32.process(x)
     assert g.num_stages(0) == ref.num_stages
     saw_bad = False
     for k in range(ref.num_stages):
@@ -1494,7 +1505,9 @@ def test_non_finite_samples_propagate_like_the_reference(pkg, ora, gpu_required,
         saw_bad = saw_bad or not np.all(np.isfinite(sr))
         fin = np.isfinite(sr)
         if np.any(fin) and ref.stage_info(k)["count"]:
-            assert_psd_close(sg[fin], sr[fin], f"N={n} stage {k} with a non-finite sample upstream")
+            s32 = np.asarray(r32.stage_spectrum(k), dtype=np.float64)
+            assert_psd_close(sg[fin], sr[fin], f"N={n} stage {k} with a non-finite sample upstream",
+                             ref_f32=s32[fin] if np.array_equal(np.isfinite(s32), fin) else None)
     assert saw_bad  # (the sums never recover: every bin of stage 0 is non-finite from that segment on)
     g.close()
     h = pkg.PsdCascadeBank(n)  # a fresh cascade (the binaries reset by dropping it) is clean
