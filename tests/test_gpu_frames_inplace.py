@@ -110,6 +110,38 @@ def test_frames_in_place_errors(pkg, ora, gpu_required):
         g.close()
 
 
+@pytest.mark.parametrize("n,batches", [(1024, 22), (4096, 7), (256, 31)])
+def test_contiguous_frame_calls_merge_into_one_run(pkg, ora, gpu_required, n, batches):
+    """PSDC_OPT_MERGE for frames: a run of AdcDac frames that continues the held run in memory (a capture ring handed over piece by
+    piece: calls of one frame up to a few hundred) extends the four traces' spans instead of adding spans -- bit-identical accumulators
+    and pending samples to the same buffer handed over in ONE call, Loss counted per call all the same, every trace against the oracle."""
+    import torch
+    nframes = max(600, (40 * n) // (8 * batches))
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=n + batches, seq0=0xFFFFFF00)
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    one, many = pkg.PsdCascadeBank(n, 4), pkg.PsdCascadeBank(n, 4)
+    assert one.process_adcdac_frames_device(d.data_ptr(), fs, nframes) == nframes
+    rng = np.random.default_rng(n)
+    pos = 0
+    first = -(-4 * (n + 288) // (8 * batches)) + 1  # (the first call long enough to be read in place: nothing to extend yet)
+    while pos < nframes:
+        m = first if pos == 0 else int(min(nframes - pos, rng.choice([1, rng.integers(1, 20), rng.integers(20, 300)])))
+        assert many.process_adcdac_frames_device(d.data_ptr() + pos * fs, fs, m) == m
+        pos += m
+    assert one.loss() == many.loss() == {"received": nframes * batches, "dropped": 0}
+    for c in range(4):
+        ns = one.num_stages(c)
+        assert many.num_stages(c) == ns
+        for k in range(ns):
+            assert many.stage_info(c, k) == one.stage_info(c, k)
+            assert np.array_equal(many.stage_spectrum(c, k).view(np.uint32), one.stage_spectrum(c, k).view(np.uint32)), (c, k)
+            assert np.array_equal(many.stage_buf(c, k).view(np.uint32), one.stage_buf(c, k).view(np.uint32)), (c, k)
+        check_against_oracle(pkg, ora, many, [traces[c]], n, channel=c, what=f"merged frame calls, trace {c}")
+    one.close()
+    many.close()
+
+
 def test_headers_may_change_once_the_call_has_returned(pkg, ora, gpu_required):
     """include/psdcascade.h, psdc_process_adcdac_frames_device, Lifetime: the verdict launch is the only reader of the 8 header
     bytes and has completed when the call returns -- the payload is read later (held spans share rounds; the tail of a span is
