@@ -506,7 +506,10 @@ void Round::share_workgroups()
     // Fused jobs per launch: all MAX_JOBS for a single channel (a round of sixty-four scattered spans is then ONE launch), 128 for
     // several channels -- eight channels x eight spans (208 jobs) measured 4 % SLOWER as one launch of 160 + one of 48 than as 128 + 80
     // (658 vs 685-691 GS/s, kernel-only 0.335 vs 0.352: each launch gets the one run length that fills the GPU for ITS jobs)
-    fused_jpl = h->n_channels == 1 ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, 128);
+#ifndef PSDK_MULTI_JPL
+#define PSDK_MULTI_JPL 128
+#endif
+    fused_jpl = h->n_channels == 1 ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, PSDK_MULTI_JPL);
     for (size_t b0 = 0; b0 < fjobs.size(); b0 += fused_jpl) {
         const size_t b1 = std::min(fjobs.size(), b0 + fused_jpl);
         // One run length R for the whole launch: the smallest R for which the jobs' workgroups
