@@ -213,6 +213,12 @@ public:
     void set_detrend(Detrend d) { check(psdc_set_detrend(h_, static_cast<int>(d))); }
     void process(std::span<const float> x) { check(psdc_process(h_, 0, x.data(), x.size())); }
     void process_device(const float *d_x, size_t len) { check(psdc_process_device(h_, 0, d_x, len)); }
+    // how device spans share rounds (include/psdcascade.h): held until `n` spans / 2^29 samples or a call that cannot join -- a function
+    // of the calls alone, so the same calls give the same bits; eager(true): also sent out when the device is seen idle (timing-dependent);
+    // merge(false): a span that continues the held one in memory becomes a span of its own instead of extending it
+    void coalesce(int n) { check(psdc_configure(h_, PSDC_OPT_COALESCE, n)); }
+    void eager(bool on) { check(psdc_configure(h_, PSDC_OPT_EAGER, on ? 1 : 0)); }
+    void merge(bool on) { check(psdc_configure(h_, PSDC_OPT_MERGE, on ? 1 : 0)); }
     psdc_handle *handle() const { return h_; } // for the batched feeders of source.hpp
     // the multi-GPU read-out record (psdc_pack_readout): gather with any transport, stitch with psd_from_readout
     std::vector<unsigned char> pack_readout() const
