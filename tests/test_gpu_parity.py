@@ -1235,6 +1235,45 @@ def test_producer_on_another_stream(pkg, ora, gpu_required):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,slot_log2,slots,laps", [(1024, 16, 8, 5), (512, 13, 16, 6)])
+def test_ring_buffer_handed_over_slot_by_slot(pkg, ora, gpu_required, n, slot_log2, slots, laps):
+    """The use the span merging is for: a producer on another stream fills a ring of `slots` adjacent slots and hands every slot over as it
+    lands (psdc_process_device_after with the slot's event).  Consecutive slots continue each other in memory and extend ONE held span
+    (PSDC_OPT_MERGE); the wrap to slot 0 starts a new span; before the producer overwrites a lap's slots it waits for a consumed event
+    (psdc_record_consumed), which sends out whatever is held.  The spectra are those of the stream as it was produced, and the whole run
+    needs about one round per lap, not one per slot."""
+    import torch
+    m = 1 << slot_log2
+    side = torch.cuda.Stream()
+    g = pkg.PsdCascadeBank(n)
+    g.configure(profile=True)
+    ring = torch.empty(m * slots, dtype=torch.float32, device="cuda")
+    chunks = []
+    consumed = None
+    for lap in range(laps):
+        for i in range(slots):
+            xh = pkg.noise_host(m, seed=9000 + 100 * lap + i)
+            chunks.append(xh)
+            src = torch.from_numpy(xh).pin_memory()
+            with torch.cuda.stream(side):
+                if consumed is not None and i == 0:
+                    side.wait_event(consumed)  # the library has read the previous lap for the last time
+                ring[m * i:m * (i + 1)].copy_(src, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            g.process_device(0, ring.data_ptr() + 4 * m * i, m, after=ready.cuda_event)
+            del src
+        consumed = torch.cuda.Event()
+        consumed.record()  # (creates the handle)
+        g.record_consumed(consumed.cuda_event)
+    g.sync()
+    launches = g.profile_read()["launches"]
+    assert launches <= 2 * laps + 4, f"{launches} fused launches for {laps} laps of {slots} slots: the slots did not merge"
+    check_against_oracle(pkg, ora, g, chunks, n, what=f"ring of {slots} slots x 2^{slot_log2}", pure_min_count=4)
+    g.close()
+    torch.cuda.synchronize()
+
+
 def test_count_past_two_to_the_32(pkg, gpu_required):
     """More than 2^32 segments in one stage (N = 256: 2^32 x 128 samples, about a second of ingest): the
     reference's u32 count wraps there (src/psd.rs:225); the library reports a saturated count, keeps the
