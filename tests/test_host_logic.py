@@ -402,3 +402,19 @@ def test_bench_traffic_record_is_of_the_benched_window():
     assert hann and "Hann" in hann["workload"] and "rectangular" not in hann["workload"]
     assert rect and "rectangular" in rect["workload"]
     assert hann["ratio"] > rect["ratio"]  # (1.35 against 1.20: half the transforms, the same streams)
+
+
+def test_binding_constants_match_the_header(pkg):
+    """The Python mirror's option / window / detrend / status constants are the header's (include/psdcascade.h): a binding that drifts
+    would configure the wrong thing silently (PSDC_OPT_EAGER = 5 and PSDC_OPT_MERGE = 6 are round 5's)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "psdcascade.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define (PSDC_[A-Z_0-9]+) \(?(-?\d+)\)?", hdr, re.M)}
+    for name, value in (("PSDC_OPT_QUANTUM", pkg.OPT_QUANTUM), ("PSDC_OPT_PROFILE", pkg.OPT_PROFILE), ("PSDC_OPT_COALESCE", pkg.OPT_COALESCE),
+                        ("PSDC_OPT_MIN_PAIRS", pkg.OPT_MIN_PAIRS), ("PSDC_OPT_EAGER", pkg.OPT_EAGER), ("PSDC_OPT_MERGE", pkg.OPT_MERGE)):
+        assert defs[name] == value, name
+    assert len({defs[k] for k in defs if k.startswith("PSDC_OPT_")}) == len([k for k in defs if k.startswith("PSDC_OPT_")])  # no two options share a number
+    assert defs["PSDC_WINDOW_HANN"] == int(pkg.Window.HANN) and defs["PSDC_WINDOW_RECTANGULAR"] == int(pkg.Window.RECTANGULAR)
+    for d in ("NONE", "MIDPOINT", "SPAN", "MEAN"):
+        assert defs[f"PSDC_DETREND_{d}"] == int(pkg.Detrend[d])
+    assert defs["PSDC_ABI_VERSION"] == pkg.lib().psdc_abi_version()
