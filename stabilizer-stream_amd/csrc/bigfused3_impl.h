@@ -134,9 +134,7 @@ __global__ __launch_bounds__(Big3Geo<N>::THREADS, Big3Geo<N>::WPS) void bigfused
             }
         }
     }
-    int ji = 0;
-    while (ji + 1 < batch.njobs && bid >= batch.jobs[ji + 1].block_begin)
-        ++ji;
+    const int ji = job_of_unit(batch, bid, [](const FusedJob &j) { return j.block_begin; });
     const FusedJob &job = batch.jobs[ji];
     const int wb = bid - job.block_begin;
     const int npairs = job.npairs, run = job.run;

@@ -109,9 +109,137 @@ __device__ __forceinline__ float team_sum(float v)
 // 2i into sixteen kept registers, step 2i + 1 windows segment 2i + 1 into the imaginary parts and runs the ONE transform of
 // both (|X_a[k]|^2 + |X_b[k]|^2 = 1/2 (|Z[k]|^2 + |Z[N-k]|^2), folded by post_kernel as ever): half the FFT work per sample of
 // the Hann path; the decimator runs every step as before.  Jobs and runs hold an even number of segments (the planner sees to it).
+#ifndef PSDK_FOLD
+#define PSDK_FOLD 1 // one launch per round for the team kernels (planner.cpp run_launches); 0: the hooks compiled out (A/B)
+#endif
+#if PSDK_FOLD
+// The aux workgroups of a one-launch round (kernels.h FusedAux): post_kernel's two roles on this kernel's workgroup size, with the
+// team frames' LDS as the reduce's scratch.  The SAME sum as post_kernel's reduce_body, addition by addition -- 32 slices of the
+// partial list (slice s: rows s, s + 32, ... in order), then the slices in order; half the bins a workgroup -- so a round gives the
+// same bits through either (tests/test_gpu_parity.py test_one_launch_rounds_give_the_same_bits).  The rows of a slice are loaded
+// four at a time and added one at a time: the loop is latency-bound and these workgroups hold a compute workgroup's slot.
+template <int THREADS>
+__device__ __forceinline__ void fused_aux_role(const FusedAux &aux, int b, double *scratch)
+{
+    constexpr int SLICES = 32, BINS = THREADS / SLICES; // (kernels.hip RED_SLICES)
+    static_assert(BINS == AUX_RED_BINS, "the host sizes the aux grid by AUX_RED_BINS");
+    const int n = aux.n, lane = threadIdx.x % BINS, slice = threadIdx.x / BINS;
+    const int tall_blocks = aux.nred_tall * aux.red_xb, mid_blocks = aux.nred_mid * aux.red_mb;
+    if (b < tall_blocks) { // a job of many rows (stage 0 of a long round): 16 bins a workgroup
+        const RedJob &job = aux.red[b / aux.red_xb];
+        const int k = (b % aux.red_xb) * BINS + lane;
+        const bool live = k <= n / 2;
+        double acc = 0.0;
+        if (live) {
+            const int km = k ? n - k : 0;
+            int t = slice;
+            for (; t + 3 * SLICES < job.nparts; t += 4 * SLICES) {
+                float v[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *p = job.partial + (size_t)(t + u * SLICES) * n;
+                    v[u][0] = p[k];
+                    v[u][1] = p[km];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc += (double)v[u][0] + (double)v[u][1];
+            }
+            for (; t < job.nparts; t += SLICES) {
+                const float *p = job.partial + (size_t)t * n;
+                acc += (double)p[k] + (double)p[km];
+            }
+        }
+        scratch[slice * (BINS + 1) + lane] = acc;
+        __syncthreads();
+        if (slice == 0 && live) {
+            acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < SLICES; ++i)
+                acc += scratch[i * (BINS + 1) + lane];
+            job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+        }
+        return;
+    }
+    b -= tall_blocks;
+    if (b < mid_blocks) { // at most two rows a slice: AUX_MID_GROUPS groups of 16 bins a workgroup, every load in flight at once,
+        const RedJob &job = aux.red[aux.nred_tall + b / aux.red_mb]; // then group g's slices are summed by the threads of slice g
+        const int g0 = (b % aux.red_mb) * AUX_MID_GROUPS;
+        float v[AUX_MID_GROUPS][2][2];
+        const bool r0 = slice < job.nparts, r1 = slice + SLICES < job.nparts;
+#pragma unroll
+        for (int g = 0; g < AUX_MID_GROUPS; ++g) {
+            const int k = (g0 + g) * BINS + lane;
+            if (k <= n / 2) {
+                const int km = k ? n - k : 0;
+                if (r0) {
+                    v[g][0][0] = job.partial[(size_t)slice * n + k];
+                    v[g][0][1] = job.partial[(size_t)slice * n + km];
+                }
+                if (r1) {
+                    v[g][1][0] = job.partial[(size_t)(slice + SLICES) * n + k];
+                    v[g][1][1] = job.partial[(size_t)(slice + SLICES) * n + km];
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < AUX_MID_GROUPS; ++g) {
+            double acc = 0.0;
+            if ((g0 + g) * BINS + lane <= n / 2) {
+                if (r0)
+                    acc += (double)v[g][0][0] + (double)v[g][0][1];
+                if (r1)
+                    acc += (double)v[g][1][0] + (double)v[g][1][1];
+            }
+            scratch[(g * SLICES + slice) * (BINS + 1) + lane] = acc;
+        }
+        __syncthreads();
+        const int k = (g0 + slice) * BINS + lane;
+        if (slice < AUX_MID_GROUPS && k <= n / 2) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < SLICES; ++i)
+                acc += scratch[(slice * SLICES + i) * (BINS + 1) + lane];
+            job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+        }
+        return;
+    }
+    b -= mid_blocks;
+    if (b < aux.nred - aux.nred_tall - aux.nred_mid) { // a job of few rows (a deep stage): one workgroup, a thread per bin; each row
+        const RedJob &job = aux.red[aux.nred_tall + aux.nred_mid + b]; // is a slice of its own, so the sum over slices is the sum over rows
+        for (int k = threadIdx.x; k <= n / 2; k += THREADS) {
+            const int km = k ? n - k : 0;
+            float v[AUX_SHORT_ROWS][2];
+#pragma unroll
+            for (int t = 0; t < AUX_SHORT_ROWS; ++t)
+                if (t < job.nparts) {
+                    v[t][0] = job.partial[(size_t)t * n + k];
+                    v[t][1] = job.partial[(size_t)t * n + km];
+                }
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < AUX_SHORT_ROWS; ++t)
+                if (t < job.nparts)
+                    acc += (double)v[t][0] + (double)v[t][1];
+            job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc);
+        }
+        return;
+    }
+    const TailJob &job = aux.tail[b - (aux.nred - aux.nred_tall - aux.nred_mid)];
+    for (int i = threadIdx.x; i < job.count; i += THREADS)
+        job.dst[i] = job.src[i];
+}
+#define PSDK_FOLD_PARAM , const FusedAux aux
+#ifndef PSDK_PRE_SCOPE
+#define PSDK_PRE_SCOPE "workgroup"
+#endif
+#else
+#define PSDK_FOLD_PARAM
+#endif
+
 template <int N, int DETREND, bool EWMA, bool FRAMES = false, int SINGLE = 0>
 __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVES_PER_SIMD) void fused_kernel(
-    const FusedBatch batch, const float *__restrict__ win)
+    const FusedBatch batch, const float *__restrict__ win PSDK_FOLD_PARAM)
 {
     using G = FusedGeo<N>;
     using T = TeamFft<N>;
@@ -122,6 +250,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     __shared__ float4 s_win[N / 4]; // window: float4 piece m of team-lane tl at [TEAM m + tl]
     __shared__ float s_hist[TEAMS * G::HIST];
 
+#if PSDK_FOLD
+    if ((int)blockIdx.x < aux.nblocks) { // (uniform: the whole workgroup takes the aux role and leaves)
+        fused_aux_role<FUSED_WAVES * 64>(aux, (int)blockIdx.x, reinterpret_cast<double *>(s_frames));
+        return;
+    }
+#endif
 #ifdef PSDK_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -145,7 +279,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     for (int i = tid; i < N / 4; i += FUSED_WAVES * 64)
         s_win[i] = *reinterpret_cast<const float4 *>(win + 4 * i); // (src/psd.rs:44-48 table)
 
+#if PSDK_FOLD
+    int bid = (int)blockIdx.x - aux.nblocks;
+#else
     int bid = blockIdx.x;
+#endif
     if constexpr (FRAMES) { // the four traces of a frame span on one XCD (see bigfused_impl.h)
         for (int g = 0; g < batch.n_fgroups; ++g) {
             const int b0 = batch.fg_begin[g], nb = batch.fg_nb[g];
@@ -165,12 +303,26 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
             }
         }
     }
-    int ji = 0;
-    while (ji + 1 < batch.njobs && bid >= batch.jobs[ji + 1].block_begin)
-        ++ji;
+    const int ji = job_of_unit(batch, bid, [](const FusedJob &j) { return j.block_begin; });
     const FusedJob &job = batch.jobs[ji];
     const int wb = bid - job.block_begin;
     const int npairs = job.npairs, run = job.run;
+#if PSDK_FOLD
+    // copy prologue of a single-workgroup job (the seam: the head of a new span behind the carried tail): nobody else reads these
+    // samples in this launch, so the hand-over is inside the workgroup -- stores, workgroup-scope release, the barrier below, acquire.
+    // (Workgroup scope is enough because the wavefronts of a workgroup share one CU and its write-through vector L1 -- no
+    // threadgroup-split mode here -- and it compiles to the waits alone; at agent scope each of these jobs wrote the XCD's L2 back
+    // and invalidated its L1, and a round of 64 such jobs took 38 us instead of 17.)
+    const bool has_pre = job.pre_count != 0;
+    if (has_pre) {
+        for (int q = 0; q < job.pre_count; ++q) {
+            const TailJob &t = aux.tail[job.pre_first + q];
+            for (int i = tid; i < t.count; i += FUSED_WAVES * 64)
+                t.dst[i] = t.src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, PSDK_PRE_SCOPE);
+    }
+#endif
 
     cf *frame = s_frames + team * T::FRAME;
     float *sf = reinterpret_cast<float *>(frame);
@@ -194,6 +346,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
         q[s] = 0.0f;
 
     __syncthreads(); // tables ready
+#if PSDK_FOLD
+    if (has_pre)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PSDK_PRE_SCOPE);
+#endif
 #ifdef PSDK_STAMPS
     const bool stamp_on = wb == 0 && run >= 8 && tid < 64; // first workgroup of a long-run job
     unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -670,6 +826,8 @@ bool fused_supported(int n)
 
 bool fused_frames_supported(int n) { return fused_supported(n); }
 
+bool fused_fold_supported(int n) { return PSDK_FOLD != 0 && (n == 256 || n == 512 || n == 1024); }
+
 // overlap 0: the sizes whose kernels have the DOUBLE form (FusedBatch::single == 2)
 bool fused_double_supported(int n) { return fused_supported(n); }
 
@@ -765,34 +923,46 @@ void fused_big3_table(int n, std::vector<cf> &tw3)
 }
 
 template <int N>
-static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+static hipError_t launch_fused_n(const FusedBatch &b, const float *win, hipStream_t s, hipEvent_t ea, hipEvent_t eb, const FusedAux *auxp)
 {
+#if PSDK_FOLD
+    static const FusedAux no_aux{};
+    const FusedAux &aux = auxp ? *auxp : no_aux;
+#define PSDK_FOLD_ARG , aux
+#else
+    (void)auxp;
+#define PSDK_FOLD_ARG
+#endif
 
     static_assert(FusedGeo<N>::LDS_BYTES * (4 * FUSED_WAVES_PER_SIMD / FUSED_WAVES) <= 163840,
                   "the workgroups of a CU (two of eight waves by default) share its 160 KiB of LDS");
+#if PSDK_FOLD
+    const dim3 grid(b.nblocks + aux.nblocks), block(FUSED_WAVES * 64);
+#else
     const dim3 grid(b.nblocks), block(FUSED_WAVES * 64);
+#endif
     const bool ew_ = b.any_ewma || (dbg_variant() & 1), frm_ = b.any_frames || (dbg_variant() & 2);
 #define PSDK_FUSED_CASE(D)                                                                \
     case D:                                                                               \
         if (frm_ && ew_)                                                                  \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, true>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG);  \
         else if (frm_)                                                                    \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win); \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, true>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG); \
         else if (ew_)                                                                     \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win);  \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG);  \
         else                                                                              \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win); \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG); \
         break;
 #define PSDK_FUSED_SINGLE(D)                                                                              \
     case D:                                                                                               \
         if (b.single == 2 && ew_)                                                                         \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 2>), grid, block, 0, s, ea, eb, 0, b, win);  \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 2>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG);  \
         else if (b.single == 2)                                                                           \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 2>), grid, block, 0, s, ea, eb, 0, b, win); \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 2>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG); \
         else if (ew_)                                                                                     \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 1>), grid, block, 0, s, ea, eb, 0, b, win);  \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, true, false, 1>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG);  \
         else                                                                                              \
-            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 1>), grid, block, 0, s, ea, eb, 0, b, win); \
+            hipExtLaunchKernelGGL((fused_kernel<N, D, false, false, 1>), grid, block, 0, s, ea, eb, 0, b, win PSDK_FOLD_ARG); \
         break;
     if (b.single) {
         if (b.any_frames)
@@ -828,7 +998,7 @@ hipError_t launch_bigfused3_2048(const FusedBatch &, const float *, const cf *, 
 hipError_t launch_bigfused3_4096(const FusedBatch &, const float *, const cf *, hipStream_t, hipEvent_t, hipEvent_t);
 
 hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, const cf *tw3g, hipStream_t s,
-                        hipEvent_t ea, hipEvent_t eb)
+                        hipEvent_t ea, hipEvent_t eb, const FusedAux *aux)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
@@ -842,11 +1012,11 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
     }
     switch (n) {
     case 256:
-        return launch_fused_n<256>(b, win, s, ea, eb);
+        return launch_fused_n<256>(b, win, s, ea, eb, aux);
     case 512:
-        return launch_fused_n<512>(b, win, s, ea, eb);
+        return launch_fused_n<512>(b, win, s, ea, eb, aux);
     case 1024:
-        return launch_fused_n<1024>(b, win, s, ea, eb);
+        return launch_fused_n<1024>(b, win, s, ea, eb, aux);
     case 2048:
         return launch_bigfused_2048(b, win, tw0g, twag, s, ea, eb);
     case 4096:

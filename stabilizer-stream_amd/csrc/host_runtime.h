@@ -143,8 +143,9 @@ struct psdc_handle {
     float *d_pool = nullptr;    // [n_channels][MAX_STAGES][2][pool_cap] small stream buffers (deep stages)
     size_t pool_cap = 0;        // floats per pooled buffer
     bool idle = true;           // nothing ingested since the pipeline was last drained
-    float *d_partial = nullptr;
-    size_t partial_cap = 0; // floats
+    float *d_partial = nullptr; // TWO slabs of partial_cap floats: a round writes slab partial_cur while the fold of the round before may
+    size_t partial_cap = 0;     // still be reading the other one (it rides in this round's fused launch when the round is one launch)
+    int partial_cur = 0;
     // stream buffers replaced by larger ones: work already enqueued may still read them, so they are freed
     // at the next point where the stream is known to be idle (release_retired) -- growing never waits
     std::vector<float *> retired;
@@ -167,6 +168,7 @@ struct psdc_handle {
     uint32_t stage_limit = psdrt::MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
     bool merge = true;  // PSDC_OPT_MERGE: a device span that continues the last held one in memory extends it
+    bool fold = getenv("PSDC_NO_FOLD") == nullptr; // (A/B aid, read when the handle is made: unset = one launch per round where the kernel allows)
     bool eager = false; // PSDC_OPT_EAGER: a held span goes out as soon as the device is seen idle (round composition then follows host timing)
     bool profile = false;
     std::vector<psdrt::ProfEvents> prof_pending;
@@ -228,6 +230,7 @@ int add_stage(psdc_handle *h, Channel &c);
 int pool_fspan(psdc_handle *h, const FrameSpan &fs);
 TailJob span_copy(psdc_handle *h, const DeviceSpan &sp, uint64_t from, float *dst, size_t count);
 int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra);
+void split_copy_jobs(const std::vector<TailJob> &in, std::vector<TailJob> &out); // long copies cut into pieces of 16 Ki samples
 int wait_uploads(psdc_handle *h);
 int order_upload(psdc_handle *h);
 int mark_upload(psdc_handle *h);

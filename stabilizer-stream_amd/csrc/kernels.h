@@ -19,6 +19,25 @@ namespace psdk {
 #endif
 constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
 
+#ifdef __HIPCC__
+// Launch unit (workgroup or tile) u -> its job: the last job whose first unit is <= u.  The tables are in launch order, so this is
+// a bisection -- eight dependent scalar loads for 160 jobs.  (It was a linear scan until round 5: ~0.1 us a job, paid by every
+// workgroup before its first load; at 128 jobs a launch that was 12 us.)
+template <class Batch, class First>
+__device__ __forceinline__ int job_of_unit(const Batch &b, int u, First first)
+{
+    int lo = 0, hi = b.njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (u >= first(b.jobs[mid]))
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+#endif
+
 // AdcDac frames resident in device memory as a stage-0 sample source (src/de/data.rs:11-82): the four traces of a run
 // of whole frames.  Sample i of trace ch: cell = i >> 3 (one 16-byte (batch, channel) cell = 8 i16 samples, src/de/data.rs:13),
 // frame = cell / batches, batch = cell % batches, at frames + frame * frame_size + 8 + batch * 64 + ch * 16 + (i & 7) * 2;
@@ -122,6 +141,7 @@ struct FusedJob {
     int ewma;
     int fspan = -1, fch = 0; // as in SegJob: src = sample s_off of trace fch of fspans[fspan] (s_off a multiple of 4)
     unsigned s_off = 0;
+    int pre_first = 0, pre_count = 0; // copy prologue of this (single-workgroup) job: FusedAux::tail[pre_first .. pre_first + pre_count)
 };
 
 struct FusedBatch {
@@ -174,6 +194,25 @@ struct TailBatch {
     TailJob jobs[MAX_JOBS];
 };
 
+// What rides in a fused launch besides its jobs when a round is ONE launch (PSDK_FOLD, fused.hip): workgroups [0, nblocks) of the grid
+// fold the partials of the round BEFORE (the other partial slab) and carry this round's stream tails -- neither depends on anything
+// this launch writes --, and jobs [ntail, ntail + npre) of `tail` are copy PROLOGUES of single-workgroup fused jobs (the seams: the
+// head of a new span behind the carried tail), named by FusedJob::pre_first / pre_count.
+constexpr int AUX_MAX_RED = 96, AUX_MAX_TAIL = 160, AUX_RED_BINS = 16;
+constexpr int AUX_SHORT_ROWS = 4, AUX_MID_ROWS = 64, AUX_MID_GROUPS = 8; // the three shapes of a fold job, by its partial rows
+struct FusedAux {
+    int nblocks;    // aux workgroups in front of the compute workgroups: red_blocks + ntail
+    int red_blocks; // nred_tall * red_xb + nred_mid * red_mb + (nred - nred_tall - nred_mid)
+    int red_xb;     // workgroups per tall job (AUX_RED_BINS bins each)
+    int red_mb;     // workgroups per mid job (AUX_MID_GROUPS groups of AUX_RED_BINS bins each)
+    int nred, ntail, npre;
+    int n;          // FFT size
+    int nred_tall;  // red[0, nred_tall): more than AUX_MID_ROWS partial rows
+    int nred_mid;   // red[nred_tall, + nred_mid): AUX_SHORT_ROWS < rows <= AUX_MID_ROWS; the rest take ONE workgroup each
+    RedJob red[AUX_MAX_RED];
+    TailJob tail[AUX_MAX_TAIL];
+};
+
 // tile geometry (host needs it to size partial slabs and grids)
 int welch_segments_per_tile(int n);
 constexpr int WELCH_MAX_BLOCKS = 1024; // persistent workgroups per launch (4 per CU)
@@ -197,6 +236,7 @@ hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const 
 bool fused_supported(int n);                 // N = 256 ... 16384
 bool fused_frames_supported(int n);          // sizes whose fused kernel can read AdcDac frames in place
 bool fused_double_supported(int n);          // overlap 0: sizes whose kernel transforms two disjoint segments at once
+bool fused_fold_supported(int n);            // sizes whose fused kernel carries aux workgroups and job prologues (FusedAux): one launch per round
 int fused_pairs_per_block(int n, int run);   // teams per workgroup x run
 int fused_max_blocks(int n);                 // resident workgroups a launch is sized for
 int fused_block_threads(int n);              // threads of one such workgroup
@@ -207,7 +247,7 @@ void fused_big3_table(int n, std::vector<cf> &tw3);
 // ev_a / ev_b (both or neither): events that receive the kernel's own start and stop times
 // (hipExtLaunchKernelGGL), for PSDC_OPT_PROFILE
 hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *tw0g, const cf *twag, const cf *tw3g,
-                        hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr);
+                        hipStream_t s, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, const FusedAux *aux = nullptr);
 hipError_t launch_dec(const DecBatch &b, hipStream_t s);
 hipError_t launch_post(const RedBatch &red, const TailBatch &tail, hipStream_t s);
 hipError_t launch_fill_noise(float *d_x, size_t len, uint64_t seed, uint64_t first, hipStream_t s);

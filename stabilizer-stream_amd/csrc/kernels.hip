@@ -118,9 +118,7 @@ __global__ __launch_bounds__(WelchCfg<N>::BLOCK) PSDK_SCALAR_F32 void welch_kern
     __shared__ float red[Cfg::WAVES * 2];
 
     // workgroup -> job; this workgroup walks the job's tiles lt = wb, wb + nblocks, ...
-    int ji = 0;
-    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
-        ++ji;
+    const int ji = job_of_unit(batch, (int)blockIdx.x, [](const SegJob &j) { return j.block_begin; });
     const SegJob &job = batch.jobs[ji];
     const int wb = blockIdx.x - job.block_begin;
 
@@ -332,9 +330,7 @@ __device__ __forceinline__ void welch_bluestein_body(const WelchBatch &batch, in
     __shared__ cf frames[TEAMS * LdsFrame<M>::SIZE];
     __shared__ float red[Cfg::WAVES * 2];
 
-    int ji = 0;
-    while (ji + 1 < batch.njobs && (int)blockIdx.x >= batch.jobs[ji + 1].block_begin)
-        ++ji;
+    const int ji = job_of_unit(batch, (int)blockIdx.x, [](const SegJob &j) { return j.block_begin; });
     const SegJob &job = batch.jobs[ji];
     const int wb = blockIdx.x - job.block_begin;
     const int team = threadIdx.x / TEAM;
@@ -625,9 +621,7 @@ __global__ __launch_bounds__(256) void hbf_dec8_kernel(const DecBatch batch)
     __shared__ __attribute__((aligned(8))) float be[NB_OUT / 2 + 4], bo[NB_OUT / 2 + 4];
 
     const int tile = blockIdx.x;
-    int ji = 0;
-    while (ji + 1 < batch.njobs && tile >= batch.jobs[ji + 1].tile_begin)
-        ++ji;
+    const int ji = job_of_unit(batch, tile, [](const DecJob &j) { return j.tile_begin; });
     const DecJob &job = batch.jobs[ji];
     const int lt = tile - job.tile_begin;
     const long long mt0 = job.m0 + (long long)lt * DEC_TILE;
@@ -725,7 +719,20 @@ __device__ __forceinline__ void reduce_body(const RedJob &job, int n, int xblk)
     double acc = 0.0; // f64 partial sums: the fold adds no rounding of its own
     if (live) {
         const int km = k ? n - k : 0; // (n - k) mod n: n need not be a power of two
-        for (int t = slice; t < job.nparts; t += RED_SLICES) {
+        int t = slice;
+        for (; t + 3 * RED_SLICES < job.nparts; t += 4 * RED_SLICES) { // (loaded four rows at a time, added one at a time: same sum)
+            float v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *p = job.partial + (size_t)(t + u * RED_SLICES) * n;
+                v[u][0] = p[k];
+                v[u][1] = p[km];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc += (double)v[u][0] + (double)v[u][1];
+        }
+        for (; t < job.nparts; t += RED_SLICES) {
             const float *p = job.partial + (size_t)t * n;
             acc += (double)p[k] + (double)p[km];
         }

@@ -29,6 +29,7 @@ struct Span { // one contiguous source of a (channel, stage) batch
                            // seam region inside the buffer): leave it alone when buffers are re-based
     int fpool = -1;        // >= 0: the source is trace fch of frame span fs_pool[fpool] read in place (src == nullptr)
     int fch = 0;
+    int pre_first = -1, pre_count = 0; // the seam copies this (buffer-side) source needs in front of its first read: Round::seams[...]
 };
 
 struct Work {
@@ -131,6 +132,12 @@ struct Round {
     size_t fused_jpl = MAX_JOBS; // fused jobs per launch (share_workgroups)
 
     std::vector<std::vector<Region>> regions; // per channel: the seam regions of its spans
+    std::vector<TailJob> seams;               // this round's seam copies (the head of every span behind the tail it continues)
+    struct SeamRef {
+        int first = -1, count = 0;
+    };
+    std::vector<std::vector<SeamRef>> seam_ref; // per (channel, span): its copies in `seams`
+    std::vector<TailJob> tjobs;                 // this round's tail carries (book)
     std::vector<Work> works;                  // what every (channel, stage) owes this round
     std::vector<PlanFused> fjobs;
     std::vector<PlanSeg> sjobs;
@@ -144,7 +151,7 @@ struct Round {
           fast_ok(fmode != 0), single(fmode == 2), fstep(fmode == 2 ? 1 : 2), half((uint64_t)h_->n / 2),
           need_pre(HBF_HALO > (uint64_t)h_->n / 2 ? HBF_HALO - (uint64_t)h_->n / 2 : 0),
           seam(std::max<uint64_t>((uint64_t)h_->n + HBF_HALO, fmode != 0 ? need_pre + 3 * half : 0)),
-          teams((uint64_t)std::max(1, fused_pairs_per_block((int)h_->n, 1))), regions(h_->n_channels)
+          teams((uint64_t)std::max(1, fused_pairs_per_block((int)h_->n, 1))), regions(h_->n_channels), seam_ref(h_->n_channels)
     {
         static const bool no_double = getenv("PSDC_NO_DOUBLE") != nullptr;
         dbl = single && !no_double && fused_double_supported((int)h->n);
@@ -173,8 +180,11 @@ struct Round {
     void make_jobs();
     void share_workgroups();
     int place_partials();
-    int launch();
+    int launch(const FusedAux *aux);
     int book();
+    bool fold_tails() const;
+    bool fold_seams() const;
+    int run_launches();
 };
 
 int Round::place_seams()
@@ -185,55 +195,43 @@ int Round::place_seams()
     // further span gets a seam REGION of its own in the stream buffer, behind the contiguous
     // part -- the tail the span before it would have carried (read from that span's end) followed
     // by the head of the span -- so that the segments straddling two spans see contiguous memory.
-    {
-        std::vector<TailJob> seams;
-        for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
-            Channel &c = h->ch[ci];
-            if (!c.has_span())
-                continue;
-            StageState &s0 = c.st[0];
-            const size_t ns = c.spans.size();
-            // contiguous part: the carried tail + the seam of the first span
-            const uint64_t cp0 = std::min<uint64_t>(seam, c.spans[0].len);
-            size_t need = (size_t)(c.spans[0].first + cp0 - s0.buf.base);
-            regions[ci].resize(ns);
-            for (size_t i = 1; i < ns; ++i) {
-                StageState t; // the stage as it stands once span i-1 is consumed
-                t.segs = segments_for(g, c.spans[i].first);
-                t.dec = decimated_prefix(g, t.segs);
-                const uint64_t kf = keep_from(g, t);
-                if (kf < c.spans[i - 1].first)
-                    return fail(h, PSDC_ERR_DEVICE, "internal: coalesced span shorter than the carried tail");
-                regions[ci][i] = {need, kf};
-                need += (size_t)(c.spans[i].first - kf) + (size_t)std::min<uint64_t>(seam, c.spans[i].len);
-            }
-            int rc = ensure_room(h, s0, s0.buf.base + need);
-            if (rc)
-                return rc;
-            float *buf = s0.buf.p[s0.buf.cur];
-            seams.push_back(span_copy(h, c.spans[0], c.spans[0].first, buf + (c.spans[0].first - s0.buf.base), (size_t)cp0));
-            s0.buf.end = c.spans[0].first + cp0;
-            for (size_t i = 1; i < ns; ++i) {
-                const Region &r = regions[ci][i];
-                const DeviceSpan &pv = c.spans[i - 1], &sp = c.spans[i];
-                const size_t back = (size_t)(sp.first - r.base);
-                seams.push_back(span_copy(h, pv, r.base, buf + r.off, back));
-                seams.push_back(span_copy(h, sp, sp.first, buf + r.off + back, (size_t)std::min<uint64_t>(seam, sp.len)));
-            }
+    // (The copies are only COLLECTED here: run_launches decides whether they ride as prologues of the jobs that read them -- a round
+    // of one launch -- or go out in a post launch in front of the fused one.)
+    for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
+        Channel &c = h->ch[ci];
+        if (!c.has_span())
+            continue;
+        StageState &s0 = c.st[0];
+        const size_t ns = c.spans.size();
+        // contiguous part: the carried tail + the seam of the first span
+        const uint64_t cp0 = std::min<uint64_t>(seam, c.spans[0].len);
+        size_t need = (size_t)(c.spans[0].first + cp0 - s0.buf.base);
+        regions[ci].resize(ns);
+        seam_ref[ci].resize(ns);
+        for (size_t i = 1; i < ns; ++i) {
+            StageState t; // the stage as it stands once span i-1 is consumed
+            t.segs = segments_for(g, c.spans[i].first);
+            t.dec = decimated_prefix(g, t.segs);
+            const uint64_t kf = keep_from(g, t);
+            if (kf < c.spans[i - 1].first)
+                return fail(h, PSDC_ERR_DEVICE, "internal: coalesced span shorter than the carried tail");
+            regions[ci][i] = {need, kf};
+            need += (size_t)(c.spans[i].first - kf) + (size_t)std::min<uint64_t>(seam, c.spans[i].len);
         }
-        HtScope ht_post(g_ht.post);
-        int rc = launch_deferred(h, seams); // with the last round's epilogue
+        int rc = ensure_room(h, s0, s0.buf.base + need);
         if (rc)
             return rc;
-        h->fs_pool.clear(); // every job that named a pooled span has been launched; this round's jobs pool theirs afresh
-        // (the event an upload waits for -- order_upload -- is recorded only where uploads happen: hosts that feed from device memory
-        // never pay for it.  $PSDC_DBG_EAGER_EVPOST: record it behind every post launch, as through round 4 -- A/B aid)
-        static const bool eager_evpost = getenv("PSDC_DBG_EAGER_EVPOST") != nullptr;
-        if (eager_evpost) {
-            HIPCHK(h, hipEventRecord(h->ev_post, h->stream));
-            h->post_marked = true;
-        } else {
-            h->post_dirty = true; // the compute stream has work an upload must wait for: order_upload records the event then
+        float *buf = s0.buf.p[s0.buf.cur];
+        seam_ref[ci][0] = {(int)seams.size(), 1};
+        seams.push_back(span_copy(h, c.spans[0], c.spans[0].first, buf + (c.spans[0].first - s0.buf.base), (size_t)cp0));
+        s0.buf.end = c.spans[0].first + cp0;
+        for (size_t i = 1; i < ns; ++i) {
+            const Region &r = regions[ci][i];
+            const DeviceSpan &pv = c.spans[i - 1], &sp = c.spans[i];
+            const size_t back = (size_t)(sp.first - r.base);
+            seam_ref[ci][i] = {(int)seams.size(), 2};
+            seams.push_back(span_copy(h, pv, r.base, buf + r.off, back));
+            seams.push_back(span_copy(h, sp, sp.first, buf + r.off + back, (size_t)std::min<uint64_t>(seam, sp.len)));
         }
     }
     return PSDC_OK;
@@ -303,6 +301,8 @@ int Round::collect_work()
                         else
                             w.spans[w.nspans++] = {s.buf.p[s.buf.cur] + regions[ci][i].off, regions[ci][i].base,
                                                    j_lo, j_split, m_lo, m_split, true};
+                        w.spans[w.nspans - 1].pre_first = seam_ref[ci][i].first;
+                        w.spans[w.nspans - 1].pre_count = seam_ref[ci][i].count;
                     }
                     if (j_hi > j_split || m_hi > m_split) {
                         Span ip{sp.d_x, first, j_split, j_hi, m_split, m_hi, true};
@@ -453,6 +453,8 @@ void Round::make_jobs()
                 fj.nb = (int)w.ew.nb;
                 fj.is_m1 = (int)std::min<int64_t>(w.ew.i_s - 1, std::numeric_limits<int>::max());
                 fj.ewma = w.ew.ewma ? 1 : 0;
+                fj.pre_first = sp.pre_first; // (indices into Round::seams until run_launches maps them into the launch's table)
+                fj.pre_count = sp.pre_count;
                 fjobs.push_back({fj, wi});
                 add_seg(sp, sp.seg_a, fs);
                 add_seg(sp, fs + fstep * np, sp.seg_b);
@@ -589,7 +591,9 @@ int Round::place_partials()
     int rc = ensure_partial(h, blocks_total * h->n);
     if (rc)
         return rc;
-    // slab: the partials of one work are contiguous (fused first, then generic)
+    // slab: the partials of one work are contiguous (fused first, then generic); this round writes slab partial_cur, the other one may
+    // still hold the round before's partials until their fold has run (in this round's fused launch when the round is one launch)
+    float *const slab_base = h->d_partial + (size_t)h->partial_cur * h->partial_cap;
     rjobs.assign(works.size(), RedJob{});
     {
         // (the jobs of a work need not be adjacent in fjobs: frame jobs were moved to the front)
@@ -602,7 +606,7 @@ int Round::place_partials()
         for (size_t wi = 0; wi < works.size(); ++wi) {
             RedJob &rj = rjobs[wi];
             base[wi] = slab;
-            rj.partial = h->d_partial + slab;
+            rj.partial = slab_base + slab;
             rj.spectrum = h->ch[works[wi].c].st[works[wi].k].spectrum;
             rj.g_total = (float)works[wi].ew.g_total;
             rj.nparts = (int)nblk[wi];
@@ -611,18 +615,18 @@ int Round::place_partials()
         if (slab > h->partial_cap)
             return fail(h, PSDC_ERR_DEVICE, "internal: partial slab overflow");
         for (PlanFused &pf : fjobs) {
-            pf.j.partial = h->d_partial + base[pf.work];
+            pf.j.partial = slab_base + base[pf.work];
             base[pf.work] += (size_t)pf.j.nblocks * h->n;
         }
         for (PlanSeg &ps : sjobs) {
-            ps.j.partial = h->d_partial + base[ps.work];
+            ps.j.partial = slab_base + base[ps.work];
             base[ps.work] += (size_t)ps.j.nblocks * h->n;
         }
     }
     return PSDC_OK;
 }
 
-int Round::launch()
+int Round::launch(const FusedAux *aux)
 {
     // ---- launches: fused, generic welch, reduce, generic decimator -------
     // HIP events time the dominant kernel of the round (fused when present).  The fused launches
@@ -668,6 +672,10 @@ int Round::launch()
                 if ((j.fspan = fm.map(h, j.fspan)) < 0)
                     return fail(h, PSDC_ERR_DEVICE, "internal: frame span table");
             }
+            if (aux && aux->npre && j.pre_count > 0)
+                j.pre_first += aux->ntail; // its seam copies sit behind the aux workgroups' tail jobs in FusedAux::tail
+            else
+                j.pre_first = j.pre_count = 0;
             fb.jobs[fb.njobs++] = j;
         }
         static const bool no_groups = getenv("PSDC_DBG_NOGROUPS") != nullptr; // (debugging aid)
@@ -692,7 +700,7 @@ int Round::launch()
             return rc;
         {
             HtScope ht_f(g_ht.fused);
-            HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b));
+            HIPCHK(h, launch_fused((int)h->n, fb, h->d_win, h->d_tw0g, h->d_twag, h->d_tw3g, h->stream, pe.a, pe.b, aux));
         }
         if ((rc = prof_end(pe, first, false)))
             return rc;
@@ -760,7 +768,7 @@ int Round::book()
 
     // carry the small tail [keep_from, old total) of every stream that consumed or
     // received samples to the front of its other buffer, then swap
-    std::vector<TailJob> tjobs;
+    tjobs.clear();
     for (uint32_t ci = 0; ci < h->n_channels; ++ci) {
         Channel &c = h->ch[ci];
         for (uint32_t k = 0; k < c.st.size(); ++k) {
@@ -792,19 +800,139 @@ int Round::book()
             s.buf.end = s.total;
         }
     }
-    // epilogue (fold the partials, carry the tails): deferred to the next launch_deferred()
-    h->pend_red = std::move(rjobs);
-    h->pend_tail = std::move(tjobs);
     for (auto &c : h->ch) {
         c.spans.clear();
         c.submitted = false;
     }
+    h->partial_cur ^= 1;
+    return PSDC_OK;
+}
+
+// ---- one launch per round ------------------------------------------------------------------------------------------------------
+// A steady-state round used to be two launches: post_kernel (the fold of the round before, its tail carries, this round's seam copies)
+// and the fused kernel.  Where the fused kernel can carry them (fused_fold_supported: N <= 1024) the three ride in the fused launch:
+//   * the TAIL CARRIES of this round as aux workgroups of this round's launch: their sources -- the unconsumed end of each stream's
+//     current buffer, or of the caller's last span -- are not written by the launch, their destinations (the front of the other
+//     buffers) are read by nobody before the next round;
+//   * the FOLD of the round before as aux workgroups too: it reads the OTHER partial slab;
+//   * the SEAM copies as prologues of the single-workgroup jobs that read them (the buffer side of a span: a handful of segments).
+// fold_tails: this round's launch can carry aux workgroups at all; fold_seams: and the post launch in front of it can go.
+bool Round::fold_tails() const
+{
+    if (!h->fold || !fused_fold_supported((int)h->n) || fjobs.empty() || !sjobs.empty() || !djobs.empty() || fjobs.size() > fused_jpl)
+        return false;
+    size_t pieces = 0;
+    for (const TailJob &t : tjobs) {
+        if (t.fspan >= 0)
+            return false; // (a tail decoded from frames: post_kernel's copy role knows how)
+        pieces += (size_t)(t.count + 16383) / 16384;
+    }
+    return pieces <= (size_t)AUX_MAX_TAIL;
+}
+
+bool Round::fold_seams() const
+{
+    if (!fold_tails() || !h->pend_tail.empty() || h->pend_red.size() > (size_t)AUX_MAX_RED)
+        return false;
+    size_t pieces = 0;
+    for (const TailJob &t : tjobs)
+        pieces += (size_t)(t.count + 16383) / 16384;
+    if (pieces + seams.size() > (size_t)AUX_MAX_TAIL)
+        return false;
+    std::vector<char> used(seams.size(), 0);
+    for (const TailJob &t : seams)
+        if (t.fspan >= 0)
+            return false;
+    for (const PlanFused &pf : fjobs)
+        if (pf.j.pre_count > 0) {
+            if (pf.j.nblocks != 1)
+                return false; // (the hand-over of a prologue is inside ONE workgroup)
+            for (int q = 0; q < pf.j.pre_count; ++q)
+                used[(size_t)(pf.j.pre_first + q)] = 1;
+        }
+    for (char u : used)
+        if (!u)
+            return false; // (a seam nobody's prologue carries: its reader went to the generic kernels)
+    return true;
+}
+
+int Round::run_launches()
+{
+    const bool ft = fold_tails(), fs = ft && fold_seams();
+    int rc;
+    if (!fs) { // the post launch in front: the round before's epilogue with this round's seams
+        HtScope ht_post(g_ht.post);
+        if ((rc = launch_deferred(h, seams)))
+            return rc;
+    }
+    FusedAux aux{};
+    if (ft) {
+        aux.n = (int)h->n;
+        std::vector<TailJob> pieces;
+        split_copy_jobs(tjobs, pieces);
+        aux.ntail = (int)pieces.size();
+        for (size_t i = 0; i < pieces.size(); ++i)
+            aux.tail[i] = pieces[i];
+        if (fs) {
+            aux.npre = (int)seams.size();
+            for (size_t i = 0; i < seams.size(); ++i)
+                aux.tail[(size_t)aux.ntail + i] = seams[i];
+            aux.nred = (int)h->pend_red.size(); // by shape: many rows (16 bins a workgroup), up to 64 (128 bins), up to 4 (every bin)
+            auto shape_of = [](const RedJob &j) { return j.nparts > AUX_MID_ROWS ? 0 : j.nparts > AUX_SHORT_ROWS ? 1 : 2; };
+            int at = 0;
+            for (int shape = 0; shape < 3; ++shape) {
+                for (const RedJob &j : h->pend_red)
+                    if (shape_of(j) == shape)
+                        aux.red[at++] = j;
+                if (shape == 0)
+                    aux.nred_tall = at;
+                else if (shape == 1)
+                    aux.nred_mid = at - aux.nred_tall;
+            }
+            aux.red_xb = ((int)h->n / 2 + 1 + AUX_RED_BINS - 1) / AUX_RED_BINS;
+            aux.red_mb = (aux.red_xb + AUX_MID_GROUPS - 1) / AUX_MID_GROUPS;
+            aux.red_blocks = aux.nred_tall * aux.red_xb + aux.nred_mid * aux.red_mb + (aux.nred - aux.nred_tall - aux.nred_mid);
+            h->pend_red.clear();
+        }
+        aux.nblocks = aux.red_blocks + aux.ntail;
+    }
+    if ((rc = launch(ft ? &aux : nullptr)))
+        return rc;
+    // what is left of the epilogue waits for the next round (or a read-out): the fold of THIS round's partials always, its tail
+    // carries unless they rode in the launch
+    h->pend_red = std::move(rjobs);
+    if (ft)
+        h->pend_tail.clear();
+    else
+        h->pend_tail = std::move(tjobs);
+    h->post_dirty = true; // the compute stream has work an upload must wait for: order_upload records the event then
     return PSDC_OK;
 }
 
 } // namespace
 
 namespace psdrt {
+
+// The pool of frame spans that jobs name by index lives from round to round only through the deferred tail carries: at the start of
+// a round it is cut down to the spans those still name (their indices re-mapped), so that it cannot grow with the stream.
+static void compact_fs_pool(psdc_handle *h)
+{
+    std::vector<FrameSpan> keep;
+    for (TailJob &t : h->pend_tail)
+        if (t.fspan >= 0) {
+            const FrameSpan &fs = h->fs_pool[(size_t)t.fspan];
+            int idx = -1;
+            for (size_t i = 0; i < keep.size(); ++i)
+                if (keep[i].frames == fs.frames && keep[i].bytes == fs.bytes && keep[i].frame_size == fs.frame_size && keep[i].batches == fs.batches)
+                    idx = (int)i;
+            if (idx < 0) {
+                keep.push_back(fs);
+                idx = (int)keep.size() - 1;
+            }
+            t.fspan = idx;
+        }
+    h->fs_pool.swap(keep);
+}
 
 // `all`: issue odd segments of decimated stages too (read-outs); the ingest path
 // leaves them for their partner.  *did_work tells whether anything was issued;
@@ -823,6 +951,7 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
     int rc = wait_uploads(h);
     if (rc)
         return rc;
+    compact_fs_pool(h);
     Round r(h, all);
     if ((rc = r.place_seams()) || (rc = r.collect_work()))
         return rc;
@@ -832,16 +961,18 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
                 return fail(h, PSDC_ERR_DEVICE, "internal: zero-copy span left unconsumed");
             c.submitted = false;
         }
-        return PSDC_OK;
+        return launch_deferred(h, r.seams); // (no work: whatever epilogue is pending goes out now -- read-outs end here)
     }
     *did_work = true;
     if ((rc = r.size_next_stages()))
         return rc;
     r.make_jobs();
     r.share_workgroups();
-    if ((rc = r.place_partials()) || (rc = r.launch()))
+    // (the bookkeeping comes BEFORE the launches since round 5: this round's tail carries may ride in its fused launch; nothing the
+    // launches use -- job tables with absolute pointers, made above -- is touched by it)
+    if ((rc = r.place_partials()) || (rc = r.book()))
         return rc;
-    return r.book();
+    return r.run_launches();
 }
 
 // one pipeline round (ingest path)

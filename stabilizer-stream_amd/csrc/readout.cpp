@@ -281,6 +281,7 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->coalesce_auto = h->coalesce_auto;
     o->eager = h->eager;
     o->merge = h->merge;
+    o->fold = h->fold;
     o->stage_limit = h->stage_limit;
     o->min_pairs = h->min_pairs;
     auto bad = [&](const char *what) -> psdc_handle * {

@@ -309,27 +309,28 @@ TailJob span_copy(psdc_handle *h, const DeviceSpan &sp, uint64_t from, float *ds
 // not launched when the round ends: the next round starts with a copy launch of its own (the
 // zero-copy seams), and one launch does both.  Nothing on the device reads what the epilogue
 // writes before that point; host-visible state never waits for it (read-outs drain first).
-int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
+void split_copy_jobs(const std::vector<TailJob> &in, std::vector<TailJob> &out)
 {
-    // a copy job is one workgroup of post_kernel: long tails (a stage that collects a batch keeps up to
-    // PSDC_OPT_MIN_PAIRS pairs pending) are cut into pieces so that the launch does not wait on one workgroup
     constexpr int kPiece = 16384;
-    std::vector<TailJob> tails;
-    tails.reserve(h->pend_tail.size() + extra.size());
-    auto add_tail = [&](const TailJob &t) {
+    for (const TailJob &t : in)
         for (int o = 0; o < t.count; o += kPiece) {
             TailJob q = t;
             q.src = t.src ? t.src + o : nullptr;
             q.dst = t.dst + o;
             q.count = std::min(kPiece, t.count - o);
             q.s_off = t.s_off + (unsigned)o;
-            tails.push_back(q);
+            out.push_back(q);
         }
-    };
-    for (const TailJob &t : h->pend_tail)
-        add_tail(t);
-    for (const TailJob &t : extra)
-        add_tail(t);
+}
+
+int launch_deferred(psdc_handle *h, const std::vector<TailJob> &extra)
+{
+    // a copy job is one workgroup of post_kernel: long tails (a stage that collects a batch keeps up to
+    // PSDC_OPT_MIN_PAIRS pairs pending) are cut into pieces so that the launch does not wait on one workgroup
+    std::vector<TailJob> tails;
+    tails.reserve(h->pend_tail.size() + extra.size());
+    split_copy_jobs(h->pend_tail, tails);
+    split_copy_jobs(extra, tails);
     // $PSDC_DBG_SKIP_POST (timing only, WRONG results): the epilogue and the seam copies are dropped, not launched -- the upper bound of
     // what folding post_kernel's work into the fused launch can buy (one launch per round)
     static const bool skip_post = getenv("PSDC_DBG_SKIP_POST") != nullptr;
@@ -447,7 +448,7 @@ int ensure_partial(psdc_handle *h, size_t floats)
         h->d_partial = nullptr;
     }
     const size_t cap = floats + floats / 2;
-    HIPCHK(h, hipMalloc(&h->d_partial, sizeof(float) * cap));
+    HIPCHK(h, hipMalloc(&h->d_partial, sizeof(float) * 2 * cap)); // two slabs (host_runtime.h)
     h->partial_cap = cap;
     return PSDC_OK;
 }
@@ -835,7 +836,7 @@ psdc_handle *create_impl(uint32_t n, int window_kind, const float *win_in, Windo
         if ((e = hipMalloc(&h->d_bigfft, sizeof(cf) * h->bigfft_elems)) != hipSuccess)
             return dev_fail(e, "hipMalloc(big FFT frames)");
     }
-    if ((e = hipMalloc(&h->d_partial, sizeof(float) * h->partial_cap)) != hipSuccess)
+    if ((e = hipMalloc(&h->d_partial, sizeof(float) * 2 * h->partial_cap)) != hipSuccess)
         return dev_fail(e, "hipMalloc(partials)");
     {
         std::vector<cf> t0, ta;

@@ -457,11 +457,12 @@ int main(int argc, char **argv)
 {
     const uint64_t first = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const uint64_t count = argc > 2 ? strtoull(argv[2], nullptr, 10) : 40;
-    long fused = 0, pairs = 0, segs = 0, decs = 0, tails = 0, ftails = 0, fjobs = 0, launches = 0, multi = 0, maxrun = 0;
+    long fused = 0, pairs = 0, segs = 0, decs = 0, tails = 0, ftails = 0, fjobs = 0, launches = 0, multi = 0, maxrun = 0, aux = 0, one = 0, pro = 0;
     auto tally = [&] {
         fused += world().fused_jobs, pairs += world().fused_pairs, segs += world().seg_segments, decs += world().dec_jobs;
         tails += world().tail_jobs, ftails += world().tail_frame_jobs, fjobs += world().fused_frame_jobs, launches += world().fused_launches;
         multi += world().multi_block_jobs, maxrun = std::max(maxrun, world().max_run);
+        aux += world().aux_launches, one += world().one_launch_rounds, pro += world().prologue_copies;
     };
     for (uint64_t s = first; s < first + count; ++s) {
         scenario_stress(s);
@@ -482,8 +483,9 @@ int main(int argc, char **argv)
         ++g_failures;
     }
     printf("round_plan_check: seeds %llu..%llu: %ld fused launches, %ld fused jobs (%ld in several workgroups, longest run %ld) of %ld "
-           "pairs, %ld generic segments, %ld decimator jobs, %ld copy jobs (%ld from frames); %s\n",
-           (unsigned long long)first, (unsigned long long)(first + count - 1), launches, fused, multi, maxrun, pairs, segs, decs, tails, ftails,
+           "pairs, %ld generic segments, %ld decimator jobs, %ld copy jobs (%ld from frames); %ld launches with aux workgroups, %ld rounds of ONE "
+           "launch, %ld seam copies as job prologues; %s\n",
+           (unsigned long long)first, (unsigned long long)(first + count - 1), launches, fused, multi, maxrun, pairs, segs, decs, tails, ftails, aux, one, pro,
            g_failures ? "FAILED" : "every segment and every decimator output exactly once, every read inside its source");
     return g_failures ? 1 : 0;
 }

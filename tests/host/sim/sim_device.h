@@ -23,7 +23,8 @@ struct World {
     std::vector<std::string> errors;
     std::map<int, std::vector<uint8_t>> seg, dec; // times produced, by tag = channel * 16 + stage, then by index
     long fused_launches = 0, fused_jobs = 0, fused_frame_jobs = 0, fused_pairs = 0, seg_jobs = 0, seg_segments = 0, dec_jobs = 0,
-         tail_jobs = 0, tail_frame_jobs = 0, red_jobs = 0, max_run = 0, multi_block_jobs = 0, launches_over_cap = 0;
+         tail_jobs = 0, tail_frame_jobs = 0, red_jobs = 0, max_run = 0, multi_block_jobs = 0, launches_over_cap = 0, aux_launches = 0,
+         one_launch_rounds = 0, prologue_copies = 0;
     int cap_blocks = 0; // > 0: fused_max_blocks() override, so that small streams exercise run lengths > 1 and oversubscription
 };
 inline World &world()

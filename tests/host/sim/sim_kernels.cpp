@@ -21,6 +21,7 @@ using sim::world;
 bool fused_supported(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
 bool fused_frames_supported(int n) { return fused_supported(n); }
 bool fused_double_supported(int n) { return fused_supported(n); }
+bool fused_fold_supported(int n) { return n == 256 || n == 512 || n == 1024; }
 static int fused_teams(int n) { return n >= 2048 ? 1 : FUSED_WAVES * (64 / (n / 16)); } // FusedGeo<N>::TEAMS
 int fused_pairs_per_block(int n, int run) { return fused_supported(n) ? fused_teams(n) * run : 0; }
 int fused_block_threads(int n) { return n >= 2048 ? n / 16 : FUSED_WAVES * 64; }
@@ -199,13 +200,33 @@ hipError_t launch_welch_big(int n, const WelchBatch &b, const float *win, const 
 
 // ---- fused_kernel / bigfused_kernel / bigfused3_kernel -------------------------------------------------------------
 hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *, const cf *, const cf *, hipStream_t s, hipEvent_t,
-                        hipEvent_t)
+                        hipEvent_t, const FusedAux *aux)
 {
     if (b.nblocks <= 0)
         return hipSuccess;
     if (!win)
         error("launch_fused: null window");
-    sim::enqueue(s, [b, n] {
+    const FusedAux ax = aux ? *aux : FusedAux{};
+    if (aux && !fused_fold_supported(n))
+        error("launch_fused: aux workgroups at n = %d, whose kernel has none", n);
+    if (ax.nblocks != ax.red_blocks + ax.ntail || ax.nred_tall < 0 || ax.nred_mid < 0 || ax.nred_tall + ax.nred_mid > ax.nred ||
+        ax.red_blocks != ax.nred_tall * ax.red_xb + ax.nred_mid * ax.red_mb + (ax.nred - ax.nred_tall - ax.nred_mid) ||
+        (ax.nred && ax.red_mb != (ax.red_xb + AUX_MID_GROUPS - 1) / AUX_MID_GROUPS) || ax.nred > AUX_MAX_RED ||
+        ax.ntail + ax.npre > AUX_MAX_TAIL || (ax.nred && (ax.n != n || ax.red_xb != (n / 2 + 1 + AUX_RED_BINS - 1) / AUX_RED_BINS)))
+        error("launch_fused: inconsistent aux table (%d workgroups: %d fold jobs x %d + %d copies, %d prologues)", ax.nblocks, ax.nred,
+              ax.red_xb, ax.ntail, ax.npre);
+    sim::enqueue(s, [b, n, ax] {
+        // The aux workgroups run BESIDE the compute workgroups; both of their roles are modelled LAST.  The tail carries: the order
+        // that breaks if any job of this launch read what they write (it would see the stale buffer front) or wrote what they read
+        // (they would carry this launch's outputs).  The fold of the round before reads the OTHER partial slab: were it this
+        // launch's own, the jobs have by now overwritten its rows, this fold takes the new round's, and the next fold of the same
+        // rows finds them consumed (tools/planner_mutations.sh, mutation 6).  The real order is any.
+        std::vector<char> pre_used((size_t)ax.npre, 0);
+        if (ax.nblocks)
+            world().aux_launches += 1;
+        if (ax.npre || ax.nred)
+            world().one_launch_rounds += 1; // (the post launch in front of this round is gone)
+        world().prologue_copies += ax.npre;
         // (single: overlap 0 -- pair p is segment seg_a + p = samples [N p, N p + N); it still decimates [N p + N/2, N p + 3N/2))
         const int teams = fused_teams(n), hop = b.single ? n : n / 2;
         world().fused_launches += 1;
@@ -221,6 +242,22 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
             if (job.block_begin != blocks)
                 error("fused job %d: block_begin %d, expected %d", ji, job.block_begin, blocks);
             blocks += job.nblocks;
+            if (job.pre_count) { // the job's copy prologue (its seam): by its ONE workgroup, in front of its first read
+                if (job.nblocks != 1 || job.pre_first < ax.ntail || job.pre_first + job.pre_count > ax.ntail + ax.npre)
+                    error("fused job %d: prologue [%d, +%d) with %d workgroups (aux: %d copies, %d prologues)", ji, job.pre_first,
+                          job.pre_count, job.nblocks, ax.ntail, ax.npre);
+                else
+                    for (int q = 0; q < job.pre_count; ++q) {
+                        const TailJob &t = ax.tail[job.pre_first + q];
+                        world().tail_jobs += 1;
+                        if (t.fspan >= 0)
+                            error("fused job %d: a prologue that decodes frames", ji);
+                        else
+                            for (int i = 0; i < t.count; ++i)
+                                t.dst[i] = t.src[i];
+                        pre_used[(size_t)(job.pre_first + q - ax.ntail)] += 1;
+                    }
+            }
             if (job.npairs < 1 || job.run < 1 || (long long)job.nblocks * teams * job.run < job.npairs ||
                 (long long)(job.nblocks - 1) * teams * job.run >= job.npairs) {
                 error("fused job %d: %d pairs in %d workgroups of %d teams x run %d", ji, job.npairs, job.nblocks, teams, job.run);
@@ -308,6 +345,36 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
                 }
                 write_partial_row(job.partial + (size_t)wb * n, n, segs);
             }
+        }
+        for (int q = 0; q < ax.npre; ++q)
+            if (pre_used[(size_t)q] != 1)
+                error("fused launch: prologue copy %d is carried by %d jobs", q, (int)pre_used[(size_t)q]);
+        for (int ji = 0; ji < ax.ntail; ++ji) { // the aux workgroups' tail carries (see above: modelled last)
+            const TailJob &job = ax.tail[ji];
+            world().tail_jobs += 1;
+            if (job.fspan >= 0)
+                error("fused launch: aux copy %d decodes frames", ji);
+            else
+                for (int i = 0; i < job.count; ++i)
+                    job.dst[i] = job.src[i];
+        }
+        for (int ji = 0; ji < ax.nred; ++ji) {
+            const RedJob &job = ax.red[ji];
+            world().red_jobs += 1;
+            const int shape = ji < ax.nred_tall ? 0 : ji < ax.nred_tall + ax.nred_mid ? 1 : 2;
+            if (shape != (job.nparts > AUX_MID_ROWS ? 0 : job.nparts > AUX_SHORT_ROWS ? 1 : 2))
+                error("fold (aux) job %d of %d rows sits among the jobs of shape %d", ji, job.nparts, shape);
+            std::vector<double> acc((size_t)n / 2 + 1, 0.0);
+            for (int t = 0; t < job.nparts; ++t) {
+                float *row = const_cast<float *>(job.partial) + (size_t)t * n;
+                if (row[1] != 1.0f)
+                    error("fold (aux) job %d: partial row %d of %d was not written by the round before (or is folded twice)", ji, t, job.nparts);
+                row[1] = 0.0f; // consumed
+                for (int k = 0; k <= n / 2; ++k)
+                    acc[(size_t)k] += (double)row[k] + (double)row[k ? n - k : 0];
+            }
+            for (int k = 0; k <= n / 2; ++k)
+                job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc[(size_t)k]);
         }
         if (blocks != b.nblocks)
             error("fused launch: %d workgroups named by the jobs, grid of %d", blocks, b.nblocks);

@@ -745,6 +745,51 @@ def test_same_calls_same_bits(pkg, ora, gpu_required, n, nch, span_log2, nspans,
             assert be.shape == ba.shape and (not ba.size or np.max(np.abs(be - ba)) <= 4e-6 * max(1e-3, float(np.max(np.abs(ba)))))
 
 
+@pytest.mark.parametrize("n,nch,span_log2,nspans,detrend", [(1024, 1, 16, 200, "none"), (1024, 1, 22, 40, "mean"), (512, 3, 18, 60, "none"),
+                                                             (256, 1, 17, 90, "midpoint")])
+def test_one_launch_rounds_give_the_same_bits(pkg, ora, gpu_required, monkeypatch, n, nch, span_log2, nspans, detrend):
+    """A steady-state round of the team kernels (N <= 1024) is ONE launch: the fold of the round before and this round's tail carries
+    ride as extra workgroups of the fused launch, the seam copies as prologues of the jobs that read them (csrc/planner.cpp
+    run_launches, csrc/fused.hip fused_aux_role).  The same additions in the same order as the post_kernel launch they replace:
+    scattered in-place spans (every one a seam) fed to a handle made under PSDC_NO_FOLD=1 (every round through post_kernel, as
+    through round 4) and to a default one give bit-identical accumulators and pending samples at every stage -- and the oracle's."""
+    import torch
+    m = 1 << span_log2
+    xs = [make_signal(pkg, m * nspans, seed=5200 + n + c, tone=0.1 * c) for c in range(nch)]
+    slot = np.random.default_rng(n).permutation(nspans)  # span i of the stream sits in slot[i] of the buffer: rarely behind span i - 1
+    xd = []
+    for x in xs:
+        buf = np.empty_like(x)
+        for i in range(nspans):
+            buf[m * slot[i]:m * (slot[i] + 1)] = x[m * i:m * (i + 1)]
+        xd.append(torch.from_numpy(buf).cuda())
+    torch.cuda.synchronize()
+
+    def run(no_fold):
+        if no_fold:
+            monkeypatch.setenv("PSDC_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("PSDC_NO_FOLD", raising=False)
+        g = pkg.PsdCascadeBank(n, nch)
+        g.set_detrend(pkg.Detrend[detrend.upper()])
+        for i in range(nspans):
+            for c in range(nch):
+                g.process_device(c, xd[c].data_ptr() + 4 * m * int(slot[i]), m)
+        return g
+
+    a, b = run(True), run(False)
+    monkeypatch.delenv("PSDC_NO_FOLD", raising=False)
+    for c in range(nch):
+        assert a.num_stages(c) == b.num_stages(c) >= 3
+        for k in range(a.num_stages(c)):
+            assert a.stage_info(c, k) == b.stage_info(c, k)
+            assert np.array_equal(a.stage_spectrum(c, k).view(np.uint32), b.stage_spectrum(c, k).view(np.uint32)), (c, k)
+            assert np.array_equal(a.stage_buf(c, k).view(np.uint32), b.stage_buf(c, k).view(np.uint32)), (c, k)
+        check_against_oracle(pkg, ora, b, [xs[c]], n, detrend=detrend, channel=c, what=f"one-launch rounds, N={n}, channel {c}")
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("n,nch", [(1024, 1), (4096, 2), (256, 1)])
 def test_contiguous_device_calls_merge_into_one_span(pkg, ora, gpu_required, n, nch):
     """PSDC_OPT_MERGE (default): a device span that starts where the last held span of its channel ends extends it -- a buffer handed
