@@ -80,9 +80,10 @@ extern "C" {
 
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
-#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8, and for a single channel
-                             * fed in f32 spans of at most 2^25 samples as many as make a round of ~2^28 samples: 16 ... 64 -- a round
-                             * costs ~20 us whatever it holds; 1 = every span its own round).  A span is HELD until its channel holds that many or a call arrives that
+#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8 and at most 2^29 samples a
+                             * channel; a handle of ONE channel: 16 and at most 2^30 samples, and of f32 spans shorter than 2^24 samples
+                             * as many as make a round of ~2^28 samples, up to 64 -- a round costs 5 ... 20 us whatever it holds;
+                             * 1 = every span its own round).  A span is HELD until its channel holds that many or a call arrives that
                              * cannot join them (host-fed or short spans, settings changes, every read-out, psdc_flush, psdc_sync,
                              * psdc_record_consumed): which spans share a round depends on the calls alone, so results are
                              * bit-reproducible.  Held spans are caller memory the library has not read yet: the rule of
@@ -90,7 +91,7 @@ extern "C" {
                              * (-k is accepted and means k: through ABI 3's first builds it asked for exactly this hold.) */
 #define PSDC_OPT_MERGE 6 /* 1 (default): a device span that starts where the last HELD span of its channel ends (d_x == previous d_x +
                           * previous len: a ring or capture buffer handed over piece by piece) extends that span instead of becoming
-                          * one of its own -- no seam between them, whatever the call size; a channel holds back at most 2^29 samples.
+                          * one of its own -- no seam between them, whatever the call size; a span stops growing at 2^29 samples.
                           * 0: every call is a span of its own (tests of the multi-span planner). */
 #define PSDC_OPT_EAGER 5 /* 1: a held span also goes out as soon as the device is seen idle (hipStreamQuery) -- the first span of a
                           * burst starts at once instead of waiting for its round to fill, at the price of a round composition

@@ -30,8 +30,10 @@ using namespace psdk;
 constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the spectra slab
 constexpr int MAX_COALESCE = 64; // zero-copy spans of one channel in one round (the automatic depth for one channel fed in short f32 spans)
 constexpr int MAX_COALESCE_OPT = 16; // ... as an explicit PSDC_OPT_COALESCE, and for runs of AdcDac frames: a launch's frame-span table
-// ... and samples a channel holds back at most: what eight 2^26-sample spans make -- the round size the stream buffers of the deeper
-// stages are sized for; a span merged from contiguous calls stops growing here
+// ... and samples a channel holds back at most (hold_max below): what eight 2^26-sample spans make -- sixteen for a handle of ONE channel,
+// whose round is all its own (a 2^30-sample round of sixteen 2^26-sample spans reads 1.0-1.7 % above two of eight: half the launch
+// gaps and run starts a sample).  A span merged from contiguous calls stops growing at HOLD_MAX_SAMPLES either way: 2^31 bytes, so
+// every byte offset into a span fits 32 bits.
 constexpr size_t HOLD_MAX_SAMPLES = (size_t)1 << 29;
 static_assert(MAX_COALESCE_OPT <= MAX_FSPANS, "a launch's frame-span table holds every FRAMED span of a round (frame calls hold at most PSDC_OPT_COALESCE <= 16)");
 
@@ -241,6 +243,7 @@ int collect_profile(psdc_handle *h);
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len = 0);
 bool device_idle(psdc_handle *h);
 size_t held_samples(const Channel &c);
+inline size_t hold_max(const psdc_handle *h) { return h->n_channels == 1 ? 2 * HOLD_MAX_SAMPLES : HOLD_MAX_SAMPLES; }
 int settle_short_span(psdc_handle *h, Channel &c);
 bool holds_short_span(const psdc_handle *h, const Channel &c);
 bool round_full(const psdc_handle *h, const Channel &c);

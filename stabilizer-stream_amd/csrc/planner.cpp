@@ -47,7 +47,7 @@ namespace {
 struct HostTiming {
     bool on = getenv("PSDC_DBG_HOST_TIMING") != nullptr;
     double round = 0, post = 0, fused = 0, other_launch = 0;
-    unsigned long rounds = 0;
+    unsigned long rounds = 0, spans = 0, span_hist[66] = {};
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~HostTiming()
     {
@@ -55,6 +55,13 @@ struct HostTiming {
             fprintf(stderr, "host timing: %lu rounds, %.2f us a round: post launch %.2f, fused launch %.2f, other launches %.2f, planning %.2f\n",
                     rounds, 1e6 * round / rounds, 1e6 * post / rounds, 1e6 * fused / rounds, 1e6 * other_launch / rounds,
                     1e6 * (round - post - fused - other_launch) / rounds);
+        if (on && rounds) {
+            fprintf(stderr, "host timing: %lu spans held when their rounds went out; rounds by spans:", spans);
+            for (int i = 0; i < 66; ++i)
+                if (span_hist[i])
+                    fprintf(stderr, " %d: %lu", i, span_hist[i]);
+            fprintf(stderr, "\n");
+        }
     }
 } g_ht;
 struct HtScope {
@@ -345,7 +352,7 @@ int Round::size_next_stages()
             size_t grow_to = 0;
             if (c.span_max) {
                 const uint64_t round_max = std::min<uint64_t>((uint64_t)c.span_max * (c.coalesced_seen ? coalesce_limit(h, c) : 1),
-                                                              std::max<uint64_t>(c.span_max, HOLD_MAX_SAMPLES)); // (a channel never holds more)
+                                                              std::max<uint64_t>(c.span_max, hold_max(h))); // (a channel never holds more)
                 const unsigned sh = 3u * (w.k + 1);
                 grow_to = (size_t)(sh < 64 ? round_max >> sh : 0) + (size_t)4 * (h->n + HBF_HALO) + 64;
             }
@@ -941,8 +948,14 @@ int advance_round(psdc_handle *h, bool *did_work, bool all)
 {
     *did_work = false;
     HtScope ht_round(g_ht.round);
-    if (g_ht.on)
+    if (g_ht.on) {
         ++g_ht.rounds;
+        size_t ns = 0;
+        for (const Channel &c : h->ch)
+            ns += c.spans.size();
+        g_ht.spans += ns;
+        g_ht.span_hist[std::min<size_t>(ns, 65)] += 1;
+    }
     for (Channel &c : h->ch) { // a held span that never grew long enough to be read in place becomes a copy (runtime.cpp)
         int rc = settle_short_span(h, c);
         if (rc)

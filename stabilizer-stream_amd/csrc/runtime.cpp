@@ -468,9 +468,9 @@ int collect_profile(psdc_handle *h)
 }
 
 // In-place spans of a channel that may share a round.  A round costs ~20 us of launch boundaries whatever it holds (the post
-// launch and two dependent dispatches): 8 spans of 2^26 samples are 0.7 ms of kernel, 8 of 2^22 are 50 us -- so a single channel fed in
-// spans of at most 2^25 samples may hold sixteen (2^24 a call: +3 %, 2^22: +21 %; eight channels x 2^24 measured -2 % with sixteen and stay
-// at eight).  An explicit PSDC_OPT_COALESCE is taken as given.
+// launch and two dependent dispatches): 8 spans of 2^26 samples are 0.7 ms of kernel, 8 of 2^22 are 50 us -- so a single channel
+// holds sixteen (2^26 a call: +1.0-1.7 %, 2^24: +3 %, 2^22: +21 %; eight channels x 2^24 measured -2 % with sixteen and stay at eight),
+// and more of shorter spans.  An explicit PSDC_OPT_COALESCE is taken as given.
 //
 // WHICH spans share a round is a function of the call sequence alone (round 5): a joinable span is held until its channel holds
 // `coalesce_limit` of them or a call arrives that cannot join (a host-fed or short span, a settings change, a read-out, psdc_flush /
@@ -482,9 +482,10 @@ int collect_profile(psdc_handle *h)
 // device at once.
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
 {
-    if (h->coalesce_auto && h->n_channels == 1 && std::max(c.span_max, len) <= ((size_t)1 << 25)) {
-        // rounds of about 2^28 samples: sixteen spans of 2^24 ... 2^25 samples, up to sixty-four shorter ones (round 5: spans that do NOT
-        // continue each other in memory -- those merge -- at 2^22 / 2^20 / 2^18 / 2^16 samples a call: tests/host/devcall_probe "scattered")
+    if (h->coalesce_auto && h->n_channels == 1) {
+        // sixteen spans a round (2^30 samples of 2^26-sample spans: hold_max), up to sixty-four spans shorter than 2^24 samples -- rounds
+        // of about 2^28 (round 5: spans that do NOT continue each other in memory -- those merge -- at 2^22 / 2^20 / 2^18 / 2^16 samples a
+        // call: tests/host/devcall_probe "scattered")
         const size_t m = std::max<size_t>(std::max(c.span_max, len), 1);
         return (uint32_t)std::min<size_t>(MAX_COALESCE, std::max<size_t>(16, ((size_t)1 << 28) / m));
     }
@@ -524,7 +525,7 @@ size_t held_samples(const Channel &c)
     return t;
 }
 // the channel's round goes out now: as many spans as may share one, or as many samples as a round should hold
-bool round_full(const psdc_handle *h, const Channel &c) { return c.spans.size() >= coalesce_limit(h, c) || held_samples(c) >= HOLD_MAX_SAMPLES; }
+bool round_full(const psdc_handle *h, const Channel &c) { return c.spans.size() >= coalesce_limit(h, c) || held_samples(c) >= hold_max(h); }
 
 // eager handles only: nothing of this handle is executing or queued on the device (~0.1 us, tools/probes/stream_query.cpp)
 bool device_idle(psdc_handle *h) { return h->eager && hipStreamQuery(h->stream) == hipSuccess; }
@@ -1220,7 +1221,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     // grouping stays deterministic.  PSDC_OPT_MERGE = 0 turns it off (tests of the multi-span planner).
     if (h->merge && c.has_span() && c.fill == 0 && !c.submitted) {
         DeviceSpan &last = c.spans.back();
-        if (!last.framed() && last.d_x + last.len == d_x && held_samples(c) + len <= HOLD_MAX_SAMPLES) {
+        if (!last.framed() && last.d_x + last.len == d_x && last.len + len <= HOLD_MAX_SAMPLES && held_samples(c) + len <= hold_max(h)) {
             last.len += len;
             c.st[0].total += len;
             c.span_max = std::max(c.span_max, last.len);
@@ -1232,12 +1233,12 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     }
     const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
-    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them and at most HOLD_MAX_SAMPLES in all (round_full: the rule
+    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them and at most hold_max samples in all (round_full: the rule
     // is a function of the calls alone).  An EAGER handle also sends them out when it sees the device idle (the stream is asked
     // at most ONCE per call; a "busy" answer stands for the rest of the call).
     bool flush = c.submitted, known_busy = false;
     if (c.has_span()) {
-        if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len) || held_samples(c) + len > HOLD_MAX_SAMPLES ||
+        if (!in_place || c.fill > 0 || c.spans.size() >= coalesce_limit(h, c, len) || held_samples(c) + len > hold_max(h) ||
             holds_short_span(h, c)) // (a short span is held only while it can still grow: this call does not continue it)
             flush = true;
         else if (device_idle(h))

@@ -5,7 +5,7 @@
 // and "scattered" -- the same pieces in an order in which no call continues the one before it (every call a span of its own, up to
 // PSDC_OPT_COALESCE of them per round).  Prints ONE JSON line with MS/s to the drain (psdc_sync) and ns of host time per call.
 // bench.py runs it after the timed region (`device_fed_calls`).
-//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0] [only log2 size = 0: all] [PSDC_OPT_COALESCE = 0: the library's own depth]
+//   usage: devcall_probe [n = 1024] [seconds per size = 0.4] [device = 0] [eager = 0] [only log2 size = 0: all] [PSDC_OPT_COALESCE = 0: the library's own depth] [which = 0: both orders, 1: contiguous only, 2: scattered only]
 #include "psdcascade.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -25,6 +25,7 @@ int main(int argc, char **argv)
     const int eager = argc > 4 ? atoi(argv[4]) : 0;
     const int only = argc > 5 ? atoi(argv[5]) : 0;
     const int coalesce = argc > 6 ? atoi(argv[6]) : 0;
+    const int which = argc > 7 ? atoi(argv[7]) : 0;
     const size_t total = (size_t)1 << 26;
     float *d = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, total * sizeof(float)) != hipSuccess) {
@@ -37,6 +38,8 @@ int main(int argc, char **argv)
     }
     printf("{\"n\": %u, \"unit\": \"MS/s\", \"eager\": %d", n, eager);
     for (int scattered = 0; scattered < 2; ++scattered) {
+        if (which && which != scattered + 1)
+            continue;
         printf(", \"%s\": {", scattered ? "scattered" : "contiguous");
         bool first = true;
         for (int lg : {26, 24, 22, 20, 18, 16}) {
