@@ -246,7 +246,6 @@ size_t held_samples(const Channel &c);
 inline size_t hold_max(const psdc_handle *h) { return h->n_channels == 1 ? 2 * HOLD_MAX_SAMPLES : HOLD_MAX_SAMPLES; }
 int settle_short_span(psdc_handle *h, Channel &c);
 bool holds_short_span(const psdc_handle *h, const Channel &c);
-bool round_full(const psdc_handle *h, const Channel &c);
 int submit_host(psdc_handle *h, Channel &c);
 int ensure_staging(psdc_handle *h, Channel &c);
 int free_staging(psdc_handle *h, Channel &c);

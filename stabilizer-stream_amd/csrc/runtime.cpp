@@ -524,8 +524,6 @@ size_t held_samples(const Channel &c)
         t += sp.len;
     return t;
 }
-// the channel's round goes out now: as many spans as may share one, or as many samples as a round should hold
-bool round_full(const psdc_handle *h, const Channel &c) { return c.spans.size() >= coalesce_limit(h, c) || held_samples(c) >= hold_max(h); }
 
 // eager handles only: nothing of this handle is executing or queued on the device (~0.1 us, tools/probes/stream_query.cpp)
 bool device_idle(psdc_handle *h) { return h->eager && hipStreamQuery(h->stream) == hipSuccess; }
@@ -1226,14 +1224,14 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
             c.st[0].total += len;
             c.span_max = std::max(c.span_max, last.len);
             h->idle = false;
-            if (h->n_channels == 1 && (round_full(h, c) || device_idle(h)))
+            if (h->n_channels == 1 && (held_samples(c) >= hold_max(h) || device_idle(h)))
                 return advance(h);
             return PSDC_OK;
         }
     }
     const bool in_place = len >= (size_t)4 * (h->n + HBF_HALO);
     // Earlier spans of this channel must go out first -- unless this one can join them: an in-place
-    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them and at most hold_max samples in all (round_full: the rule
+    // span behind in-place spans, fewer than PSDC_OPT_COALESCE of them and at most hold_max samples in all (the rule
     // is a function of the calls alone).  An EAGER handle also sends them out when it sees the device idle (the stream is asked
     // at most ONCE per call; a "busy" answer stands for the rest of the call).
     bool flush = c.submitted, known_busy = false;
@@ -1289,8 +1287,11 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
             c.coalesced_seen = true;
     }
     if (h->n_channels == 1) {
-        if (c.has_span() && !c.submitted && !round_full(h, c) && (known_busy || !device_idle(h)))
-            return PSDC_OK; // held: the next span may share this one's round
+        // held: the next span may share this one's round, or continue this span in memory -- so a round that holds its LAST span goes
+        // out when the call arrives that cannot join it (above), not when that span starts: a buffer handed over in pieces would
+        // otherwise leave every round with the first piece of its last span (667 against 707 GS/s for 2^24-sample pieces)
+        if (c.has_span() && !c.submitted && held_samples(c) < hold_max(h) && coalesce_limit(h, c) > 1 && (known_busy || !device_idle(h)))
+            return PSDC_OK;
         return advance(h);
     }
     return PSDC_OK;
