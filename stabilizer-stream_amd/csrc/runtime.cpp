@@ -473,7 +473,7 @@ int collect_profile(psdc_handle *h)
 // and more of shorter spans.  An explicit PSDC_OPT_COALESCE is taken as given.
 //
 // WHICH spans share a round is a function of the call sequence alone (round 5): a joinable span is held until its channel holds
-// `coalesce_limit` of them or a call arrives that cannot join (a host-fed or short span, a settings change, a read-out, psdc_flush /
+// hold_max samples or a call arrives that cannot join (one span more than `coalesce_limit`, a host-fed or short span, a settings change, a read-out, psdc_flush /
 // psdc_sync / psdc_record_consumed).  Through round 4 a held span also went out as soon as hipStreamQuery saw the device idle: lower
 // latency on a trickle feed, but the grouping of the partial sums -- run lengths, the one f32 add per round -- then followed HOST
 // TIMING, and the same calls could give spectra that differ in the last bits from run to run (the driver's bench coalesced 6.8 spans
