@@ -869,6 +869,50 @@ def test_many_scattered_spans_share_a_round(pkg, ora, gpu_required, n, piece_log
     g2.close()
 
 
+def test_round_of_sixteen_full_size_spans(pkg, ora, gpu_required):
+    """BASELINE config 2's span (2^26 samples, N = 1024) seventeen times over: a handle of one channel holds sixteen such spans and
+    sends them out as ONE round of 2^30 samples (csrc/host_runtime.h hold_max; `bench.py`'s step).  The stream is too long for the
+    oracle in a test; what is checked is size-independent: nothing is launched while fifteen spans are held and ONE launch carries the
+    sixteen; the counters in closed form (src/psd.rs:196-269); the reference's own white-noise bound on every included bin of every
+    stage (src/psd.rs:634-643); and the same stream fed span by span (PSDC_OPT_COALESCE = 1: another grouping of the same sums) to
+    rounding."""
+    import torch
+    n, m, nspans, gap = 1024, 1 << 26, 17, 64  # (a gap between the spans: none continues its predecessor in memory, nothing merges)
+    d = torch.empty(nspans * (m + gap), dtype=torch.float32, device="cuda")
+    pkg.fill_noise_device(d.data_ptr(), d.numel(), seed=0xACE1)
+    torch.cuda.synchronize()
+    one, each = pkg.PsdCascadeBank(n, 1), pkg.PsdCascadeBank(n, 1)
+    one.configure(profile=True)
+    each.configure(coalesce=1)
+    for i in range(nspans):
+        one.process_device(0, d.data_ptr() + 4 * i * (m + gap), m)
+        each.process_device(0, d.data_ptr() + 4 * i * (m + gap), m)
+        if i == 14:
+            assert one.profile_read()["launches"] == 0  # fifteen spans held, nothing launched
+        if i == 15:
+            assert one.profile_read()["launches"] == 1  # 2^30 samples held: the round goes out, one launch
+    one.sync()
+    assert one.profile_read()["launches"] <= 2 + 11  # ... the seventeenth span, and the drain: a round per stage still holding samples
+    ns = one.num_stages(0)
+    assert ns == each.num_stages(0) >= 8
+    t = nspans * m
+    for k in range(ns):
+        info = one.stage_info(0, k)
+        assert info == each.stage_info(0, k)
+        assert info["count"] == ((t - n) // (n // 2) + 1 if t >= n else 0), (k, info)
+        t = (info["count"] * (n // 2) + n // 2) // 8 - 35 if info["count"] else 0  # (decimated so far, less the filters' delay: src/psd.rs:246-253)
+        a, b = one.stage_spectrum(0, k).astype(np.float64), each.stage_spectrum(0, k).astype(np.float64)
+        if info["count"]:
+            assert np.all(np.abs(a - b) <= 2e-6 * b + 5e-7 * np.sqrt(b * b.max())), k
+    p, br = one.psd(0)
+    for brk in br:
+        if brk.include and brk.count >= 4:
+            seg = p[brk.start:brk.start + len(brk.bins)]
+            assert np.all(np.abs(seg * 0.5 - 1.0) < 10.0 / np.sqrt(brk.count)), brk
+    one.close()
+    each.close()
+
+
 def test_full_size_properties(pkg, ora, gpu_required):
     """BASELINE config 2 at its full size (2^26 samples, N=1024): size-independent properties, then the f64
     oracle on the same samples."""
