@@ -216,11 +216,44 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
         error("launch_fused: inconsistent aux table (%d workgroups: %d fold jobs x %d + %d copies, %d prologues)", ax.nblocks, ax.nred,
               ax.red_xb, ax.ntail, ax.npre);
     sim::enqueue(s, [b, n, ax] {
-        // The aux workgroups run BESIDE the compute workgroups; both of their roles are modelled LAST.  The tail carries: the order
-        // that breaks if any job of this launch read what they write (it would see the stale buffer front) or wrote what they read
-        // (they would carry this launch's outputs).  The fold of the round before reads the OTHER partial slab: were it this
-        // launch's own, the jobs have by now overwritten its rows, this fold takes the new round's, and the next fold of the same
-        // rows finds them consumed (tools/planner_mutations.sh, mutation 6).  The real order is any.
+        // The aux workgroups run BESIDE the compute workgroups: the real order is any, so the model runs both of their roles behind the
+        // jobs in one launch and in front of them in the next.  Behind: breaks if a job of this launch read what the tail carries write
+        // (it would have seen the stale buffer front), and if the fold read the partial slab this launch writes (the jobs have by
+        // then overwritten its rows, this fold takes the new round's, and the next fold of the same rows finds them consumed:
+        // tools/planner_mutations.sh, mutation 6).  In front: breaks if a job wrote what the tail carries read.
+        auto aux_roles = [&] {
+            for (int ji = 0; ji < ax.ntail; ++ji) { // the aux workgroups' tail carries (see above)
+                const TailJob &job = ax.tail[ji];
+                world().tail_jobs += 1;
+                if (job.fspan >= 0)
+                    error("fused launch: aux copy %d decodes frames", ji);
+                else
+                    for (int i = 0; i < job.count; ++i)
+                        job.dst[i] = job.src[i];
+            }
+            for (int ji = 0; ji < ax.nred; ++ji) {
+                const RedJob &job = ax.red[ji];
+                world().red_jobs += 1;
+                const int shape = ji < ax.nred_tall ? 0 : ji < ax.nred_tall + ax.nred_mid ? 1 : 2;
+                if (shape != (job.nparts > AUX_MID_ROWS ? 0 : job.nparts > AUX_SHORT_ROWS ? 1 : 2))
+                    error("fold (aux) job %d of %d rows sits among the jobs of shape %d", ji, job.nparts, shape);
+                std::vector<double> acc((size_t)n / 2 + 1, 0.0);
+                for (int t = 0; t < job.nparts; ++t) {
+                    float *row = const_cast<float *>(job.partial) + (size_t)t * n;
+                    if (row[1] != 1.0f)
+                        error("fold (aux) job %d: partial row %d of %d was not written by the round before (or is folded twice)", ji, t, job.nparts);
+                    row[1] = 0.0f; // consumed
+                    for (int k = 0; k <= n / 2; ++k)
+                        acc[(size_t)k] += (double)row[k] + (double)row[k ? n - k : 0];
+                }
+                for (int k = 0; k <= n / 2; ++k)
+                    job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc[(size_t)k]);
+            }
+        };
+        static unsigned long aux_launch = 0;
+        const bool aux_first = ax.nblocks && (aux_launch++ & 1); // (every other launch that has aux workgroups)
+        if (aux_first)
+            aux_roles();
         std::vector<char> pre_used((size_t)ax.npre, 0);
         if (ax.nblocks)
             world().aux_launches += 1;
@@ -349,33 +382,8 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
         for (int q = 0; q < ax.npre; ++q)
             if (pre_used[(size_t)q] != 1)
                 error("fused launch: prologue copy %d is carried by %d jobs", q, (int)pre_used[(size_t)q]);
-        for (int ji = 0; ji < ax.ntail; ++ji) { // the aux workgroups' tail carries (see above: modelled last)
-            const TailJob &job = ax.tail[ji];
-            world().tail_jobs += 1;
-            if (job.fspan >= 0)
-                error("fused launch: aux copy %d decodes frames", ji);
-            else
-                for (int i = 0; i < job.count; ++i)
-                    job.dst[i] = job.src[i];
-        }
-        for (int ji = 0; ji < ax.nred; ++ji) {
-            const RedJob &job = ax.red[ji];
-            world().red_jobs += 1;
-            const int shape = ji < ax.nred_tall ? 0 : ji < ax.nred_tall + ax.nred_mid ? 1 : 2;
-            if (shape != (job.nparts > AUX_MID_ROWS ? 0 : job.nparts > AUX_SHORT_ROWS ? 1 : 2))
-                error("fold (aux) job %d of %d rows sits among the jobs of shape %d", ji, job.nparts, shape);
-            std::vector<double> acc((size_t)n / 2 + 1, 0.0);
-            for (int t = 0; t < job.nparts; ++t) {
-                float *row = const_cast<float *>(job.partial) + (size_t)t * n;
-                if (row[1] != 1.0f)
-                    error("fold (aux) job %d: partial row %d of %d was not written by the round before (or is folded twice)", ji, t, job.nparts);
-                row[1] = 0.0f; // consumed
-                for (int k = 0; k <= n / 2; ++k)
-                    acc[(size_t)k] += (double)row[k] + (double)row[k ? n - k : 0];
-            }
-            for (int k = 0; k <= n / 2; ++k)
-                job.spectrum[k] = job.g_total * job.spectrum[k] + (float)(0.5 * acc[(size_t)k]);
-        }
+        if (!aux_first)
+            aux_roles();
         if (blocks != b.nblocks)
             error("fused launch: %d workgroups named by the jobs, grid of %d", blocks, b.nblocks);
         if (big_blocks > fused_max_blocks(n))
