@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--window", default="hann", choices=["hann", "rectangular", "hamming"],
                     help="hann (the configs'), rectangular (overlap 0: the fused kernels, two disjoint segments per transform) or a caller-built Hamming table with overlap N/2")
     ap.add_argument("--coalesce", type=int, default=None,
-                    help="PSDC_OPT_COALESCE: in-place spans of a channel that share a round (library default 8; 16 for one channel fed in spans <= 2^25)")
+                    help="PSDC_OPT_COALESCE: in-place spans of a channel that share a round (library default 8; a handle of one channel 16, and more of spans shorter than 2^24 samples)")
     ap.add_argument("--eager", action="store_true", help="PSDC_OPT_EAGER: held spans go out when the device is seen idle (timing-dependent rounds; A/B aid)")
     ap.add_argument("--min-pairs", type=int, default=None, help="PSDC_OPT_MIN_PAIRS (library default 32 x teams per workgroup)")
     ap.add_argument("--avg", default=None, help="finite averaging 'limit,count' (AvgOpts, src/psd.rs:360-376); default: plain sum")

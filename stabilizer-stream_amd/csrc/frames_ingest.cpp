@@ -371,7 +371,7 @@ int psdc_process_adcdac_frames_device(psdc_handle *h, const uint8_t *d_frames, s
                     can = c.has_span() && c.fill == 0 && !c.submitted && c.spans.back().framed() && c.spans.back().fch == ci &&
                           c.spans.back().fs.frames + c.spans.back().fs.bytes == piece && c.spans.back().fs.frame_size == (unsigned)frame_size &&
                           c.spans.back().fs.batches == (unsigned)batches && c.spans.back().fs.frames == h->ch[0].spans.back().fs.frames &&
-                          c.spans.back().len + per_ch <= (size_t)FSPAN_MAX_SAMPLES && held_samples(c) + per_ch <= HOLD_MAX_SAMPLES;
+                          c.spans.back().len + per_ch <= (size_t)FSPAN_MAX_SAMPLES && held_samples(c) + per_ch <= hold_max(h);
                 }
                 if (can) {
                     for (int ci = 0; ci < 4; ++ci) {

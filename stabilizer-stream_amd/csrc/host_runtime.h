@@ -35,6 +35,12 @@ constexpr int MAX_COALESCE_OPT = 16; // ... as an explicit PSDC_OPT_COALESCE, an
 // gaps and run starts a sample).  A span merged from contiguous calls stops growing at HOLD_MAX_SAMPLES either way: 2^31 bytes, so
 // every byte offset into a span fits 32 bits.
 constexpr size_t HOLD_MAX_SAMPLES = (size_t)1 << 29;
+inline size_t hold_cap_from_env()
+{
+    const char *e = getenv("PSDC_DBG_HOLD_LOG2"); // (testing aid: tests/host/round_plan_check.cpp reaches the caps with streams of a few million samples)
+    const long v = e ? strtol(e, nullptr, 10) : 0;
+    return v >= 12 && v <= 29 ? (size_t)1 << v : HOLD_MAX_SAMPLES;
+}
 static_assert(MAX_COALESCE_OPT <= MAX_FSPANS, "a launch's frame-span table holds every FRAMED span of a round (frame calls hold at most PSDC_OPT_COALESCE <= 16)");
 
 extern thread_local std::string g_last_error;
@@ -169,6 +175,7 @@ struct psdc_handle {
     bool coalesce_auto = true; // PSDC_OPT_COALESCE not set: `coalesce`, or 16 ... MAX_COALESCE for one channel fed in short spans (coalesce_limit)
     uint32_t stage_limit = psdrt::MAX_STAGES; // stages that analyse their stream; 1 for a single Psd<N> (psdc_stage_*)
     uint32_t min_pairs = 0; // PSDC_OPT_MIN_PAIRS: segment pairs a decimated stage collects before it issues on the ingest path
+    size_t span_cap = psdrt::hold_cap_from_env(); // HOLD_MAX_SAMPLES ($PSDC_DBG_HOLD_LOG2, read when the handle is made: the CPU model's streams are short)
     bool merge = true;  // PSDC_OPT_MERGE: a device span that continues the last held one in memory extends it
     bool fold = getenv("PSDC_NO_FOLD") == nullptr; // (A/B aid, read when the handle is made: unset = one launch per round where the kernel allows)
     bool eager = false; // PSDC_OPT_EAGER: a held span goes out as soon as the device is seen idle (round composition then follows host timing)
@@ -243,7 +250,7 @@ int collect_profile(psdc_handle *h);
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len = 0);
 bool device_idle(psdc_handle *h);
 size_t held_samples(const Channel &c);
-inline size_t hold_max(const psdc_handle *h) { return h->n_channels == 1 ? 2 * HOLD_MAX_SAMPLES : HOLD_MAX_SAMPLES; }
+inline size_t hold_max(const psdc_handle *h) { return h->n_channels == 1 ? 2 * h->span_cap : h->span_cap; }
 int settle_short_span(psdc_handle *h, Channel &c);
 bool holds_short_span(const psdc_handle *h, const Channel &c);
 int submit_host(psdc_handle *h, Channel &c);

@@ -282,6 +282,7 @@ psdc_handle *psdc_clone(psdc_handle *h)
     o->eager = h->eager;
     o->merge = h->merge;
     o->fold = h->fold;
+    o->span_cap = h->span_cap;
     o->stage_limit = h->stage_limit;
     o->min_pairs = h->min_pairs;
     auto bad = [&](const char *what) -> psdc_handle * {

@@ -1219,7 +1219,7 @@ int psdc_process_device_after(psdc_handle *h, uint32_t channel, const float *d_x
     // grouping stays deterministic.  PSDC_OPT_MERGE = 0 turns it off (tests of the multi-span planner).
     if (h->merge && c.has_span() && c.fill == 0 && !c.submitted) {
         DeviceSpan &last = c.spans.back();
-        if (!last.framed() && last.d_x + last.len == d_x && last.len + len <= HOLD_MAX_SAMPLES && held_samples(c) + len <= hold_max(h)) {
+        if (!last.framed() && last.d_x + last.len == d_x && last.len + len <= h->span_cap && held_samples(c) + len <= hold_max(h)) {
             last.len += len;
             c.st[0].total += len;
             c.span_max = std::max(c.span_max, last.len);

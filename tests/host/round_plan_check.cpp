@@ -271,7 +271,15 @@ void scenario_spans(uint64_t seed)
     const int caps[] = {0, 2, 5, 16, 64};
     const bool rect = r.f() < 0.3; // overlap 0: the single-segment form of the fused kernels
     new_scenario("spans seed " + std::to_string(seed) + " n=" + std::to_string(n) + (rect ? " rectangular" : ""), caps[r.u(0, 5)]);
+    // (two seeds in five: the caps on what a channel holds and on how far a merged span grows, HOLD_MAX_SAMPLES = 2^29 in the library,
+    // brought down to 2^16 ... 2^19 samples so that streams of a few million samples reach them)
+    const bool low_caps = seed % 5 == 2 || seed % 5 == 4;
+    if (low_caps)
+        setenv("PSDC_DBG_HOLD_LOG2", std::to_string(16 + seed / 5 % 4).c_str(), 1);
+    else
+        unsetenv("PSDC_DBG_HOLD_LOG2");
     psdc_handle *h = psdc_create(n, rect ? PSDC_WINDOW_RECTANGULAR : PSDC_WINDOW_HANN, (uint32_t)nch, 0);
+    unsetenv("PSDC_DBG_HOLD_LOG2");
     if (!h) {
         fail("psdc_create: %s", psdc_last_error(nullptr));
         return;
@@ -283,7 +291,7 @@ void scenario_spans(uint64_t seed)
     if (!deep)
         CK(psdc_configure(h, PSDC_OPT_COALESCE, (int64_t)r.u(1, 17)));
     CK(psdc_configure(h, PSDC_OPT_EAGER, !deep && r.f() < 0.4 ? 1 : 0)); // (eager: held spans go out when the modelled stream is idle)
-    CK(psdc_configure(h, PSDC_OPT_MERGE, !deep && r.f() < 0.3 ? 1 : 0));
+    CK(psdc_configure(h, PSDC_OPT_MERGE, r.f() < (deep ? 0.5 : 0.3) ? 1 : 0)); // (the feeds are slices of one array: merged they grow ONE span, up to the cap)
     if (r.f() < 0.5)
         CK(psdc_configure(h, PSDC_OPT_MIN_PAIRS, (int64_t)r.u(0, 300)));
     std::vector<uint64_t> pos((size_t)nch, 0);
