@@ -13,5 +13,6 @@ objs=""
 for m in 2048 4096 8192 16384; do
   if [ "$m" = "$n" ]; then objs="$objs $here/bigfused_${n}_stamps.o"; else objs="$objs $csrc/bigfused_$m.o"; fi
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$here/libpsdcascade_bstamps_$n.so" "$csrc/kernels.o" "$csrc/fused.o" $objs "$csrc/bigfused3_2048.o" "$csrc/bigfused3_4096.o" "$csrc/psdcascade.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$here/libpsdcascade_bstamps_$n.so" "$csrc/kernels.o" "$csrc/bigfft.o" "$csrc/fused.o" $objs "$csrc/bigfused3_2048.o" "$csrc/bigfused3_4096.o" \
+    "$csrc/runtime.o" "$csrc/planner.o" "$csrc/frames_ingest.o" "$csrc/readout.o"
 echo built "$here/libpsdcascade_bstamps_$n.so"
