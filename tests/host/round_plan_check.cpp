@@ -431,6 +431,64 @@ void scenario_single(uint64_t seed)
     psdc_stage_destroy(st);
 }
 
+// ---- when a held round goes out (csrc/runtime.cpp psdc_process_device_after): a function of the calls alone -------------
+// One channel; the caps on a merged span / on what the channel holds (2^29 / 2^30 samples in the library) brought down to 2^16 / 2^17.
+void scenario_hold_rules()
+{
+    const uint32_t n = 256;
+    const size_t piece = 4096, span = 8192; // (a span is read in place from 4 (n + 288) = 2176 samples)
+    struct Case {
+        const char *what;
+        int merge, coalesce; // coalesce 0: the library's own depth
+        bool contiguous;     // pieces of one array in order (they continue each other in memory), or every span an array of its own
+        size_t len;
+        int calls;
+        bool (*goes_out)(int i); // does call i send a round out?
+    };
+    static const Case cases[] = {
+        // pieces 0 ... 15 grow one span to its cap, 16 ... 31 a second one; the channel then holds 2^17 samples: out with piece 31, 63
+        {"hold rules: contiguous pieces merge", 1, 0, true, piece, 70, [](int i) { return i % 32 == 31; }},
+        // the library's depth for 8192-sample spans is 64; sixteen of them are 2^17 samples: out with the 16th, 32nd ... call
+        {"hold rules: scattered spans, the library's depth", 1, 0, false, span, 40, [](int i) { return i % 16 == 15; }},
+        // an explicit depth of four: the round goes out with the call that cannot join it (the fifth, ninth ...), which is then held
+        {"hold rules: four spans a round", 0, 4, false, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
+        // ... also when the spans continue each other in memory but merging is off
+        {"hold rules: four spans a round, contiguous, no merging", 0, 4, true, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
+        // depth one: nothing is ever held
+        {"hold rules: every span its own round", 1, 1, false, span, 6, [](int) { return true; }},
+    };
+    for (const Case &cs : cases) {
+        new_scenario(cs.what, 0);
+        setenv("PSDC_DBG_HOLD_LOG2", "16", 1);
+        psdc_handle *h = psdc_create(n, PSDC_WINDOW_HANN, 1, 0);
+        unsetenv("PSDC_DBG_HOLD_LOG2");
+        if (!h) {
+            fail("psdc_create: %s", psdc_last_error(nullptr));
+            continue;
+        }
+        CK(psdc_configure(h, PSDC_OPT_MERGE, cs.merge));
+        if (cs.coalesce)
+            CK(psdc_configure(h, PSDC_OPT_COALESCE, cs.coalesce));
+        const std::vector<float> x = ident_stream(0, cs.len * (size_t)cs.calls);
+        std::vector<std::vector<float>> own; // (kept alive until the sync: held spans are caller memory)
+        for (int i = 0; i < cs.calls; ++i) {
+            const float *p = x.data() + cs.len * (size_t)i;
+            if (!cs.contiguous) {
+                own.emplace_back(p, p + cs.len);
+                p = own.back().data();
+            }
+            const long before = world().fused_enqueued;
+            CK(psdc_process_device(h, 0, p, cs.len));
+            const bool went = world().fused_enqueued != before;
+            if (went != cs.goes_out(i))
+                fail("call %d: %s", i, went ? "a round went out" : "no round went out");
+        }
+        CK(psdc_sync(h));
+        verify(h, n, n / 2, 1, {(uint64_t)cs.len * (uint64_t)cs.calls}, true);
+        psdc_destroy(h);
+    }
+}
+
 // ---- failures on the way: an allocation that fails must leave a handle that still destroys cleanly ---------------------
 void scenario_alloc_failure()
 {
@@ -484,6 +542,7 @@ int main(int argc, char **argv)
             tally();
         }
     }
+    scenario_hold_rules();
     scenario_alloc_failure();
     new_scenario("end", 0);
     if (sim::rt().live_blocks != 0) {

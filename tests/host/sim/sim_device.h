@@ -25,6 +25,7 @@ struct World {
     long fused_launches = 0, fused_jobs = 0, fused_frame_jobs = 0, fused_pairs = 0, seg_jobs = 0, seg_segments = 0, dec_jobs = 0,
          tail_jobs = 0, tail_frame_jobs = 0, red_jobs = 0, max_run = 0, multi_block_jobs = 0, launches_over_cap = 0, aux_launches = 0,
          one_launch_rounds = 0, prologue_copies = 0;
+    long fused_enqueued = 0; // launch_fused calls so far (counted when the HOST makes them: what has gone out, run or not)
     int cap_blocks = 0; // > 0: fused_max_blocks() override, so that small streams exercise run lengths > 1 and oversubscription
 };
 inline World &world()

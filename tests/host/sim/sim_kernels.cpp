@@ -215,6 +215,7 @@ hipError_t launch_fused(int n, const FusedBatch &b, const float *win, const cf *
         ax.ntail + ax.npre > AUX_MAX_TAIL || (ax.nred && (ax.n != n || ax.red_xb != (n / 2 + 1 + AUX_RED_BINS - 1) / AUX_RED_BINS)))
         error("launch_fused: inconsistent aux table (%d workgroups: %d fold jobs x %d + %d copies, %d prologues)", ax.nblocks, ax.nred,
               ax.red_xb, ax.ntail, ax.npre);
+    world().fused_enqueued += 1;
     sim::enqueue(s, [b, n, ax] {
         // The aux workgroups run BESIDE the compute workgroups: the real order is any, so the model runs both of their roles behind the
         // jobs in one launch and in front of them in the next.  Behind: breaks if a job of this launch read what the tail carries write
