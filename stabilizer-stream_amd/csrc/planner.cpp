@@ -701,6 +701,16 @@ int Round::launch(const FusedAux *aux)
             ++fb.n_fgroups;
             a += 4;
         }
+        static const bool dbg_plan = getenv("PSDC_DBG_PLAN") != nullptr; // (debugging aid: what each fused launch holds)
+        if (dbg_plan) {
+            long long np = 0;
+            for (int q = 0; q < fb.njobs; ++q)
+                np += fb.jobs[q].npairs;
+            fprintf(stderr, "fused launch: %d jobs, %d workgroups (+%d aux), %lld pairs:", fb.njobs, fb.nblocks, aux ? aux->nblocks : 0, np);
+            for (int q = 0; q < fb.njobs; ++q)
+                fprintf(stderr, " %dp/%dwg/r%d%s", fb.jobs[q].npairs, fb.jobs[q].nblocks, fb.jobs[q].run, fb.jobs[q].pre_count ? "s" : "");
+            fprintf(stderr, "\n");
+        }
         ProfEvents pe{};
         const bool first = (i <= fused_jpl);
         if ((rc = prof_begin(pe, false)))
@@ -827,7 +837,7 @@ int Round::book()
 bool Round::fold_tails() const
 {
     if (!h->fold || !fused_fold_supported((int)h->n) || fjobs.empty() || !sjobs.empty() || !djobs.empty() || fjobs.size() > fused_jpl)
-        return false;
+        return false; // (a round of several fused launches: measured for eight channels x eight spans with the aux workgroups in the first of them -- -0.6 %)
     size_t pieces = 0;
     for (const TailJob &t : tjobs) {
         if (t.fspan >= 0)
