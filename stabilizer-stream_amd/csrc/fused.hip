@@ -230,6 +230,9 @@ __device__ __forceinline__ void fused_aux_role(const FusedAux &aux, int b, doubl
         job.dst[i] = job.src[i];
 }
 #define PSDK_FOLD_PARAM , const FusedAux aux
+#ifndef PSDK_AUX_BACK
+#define PSDK_AUX_BACK 0 // 1: the aux workgroups behind the compute workgroups in the grid instead of in front (A/B)
+#endif
 #ifndef PSDK_PRE_SCOPE
 #define PSDK_PRE_SCOPE "workgroup"
 #endif
@@ -251,10 +254,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     __shared__ float s_hist[TEAMS * G::HIST];
 
 #if PSDK_FOLD
+#if PSDK_AUX_BACK
+    if ((int)blockIdx.x >= batch.nblocks) { // (uniform: the whole workgroup takes the aux role and leaves)
+        fused_aux_role<FUSED_WAVES * 64>(aux, (int)blockIdx.x - batch.nblocks, reinterpret_cast<double *>(s_frames));
+        return;
+    }
+#else
     if ((int)blockIdx.x < aux.nblocks) { // (uniform: the whole workgroup takes the aux role and leaves)
         fused_aux_role<FUSED_WAVES * 64>(aux, (int)blockIdx.x, reinterpret_cast<double *>(s_frames));
         return;
     }
+#endif
 #endif
 #ifdef PSDK_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, EWMA ? PSDK_EWMA_WPS : FUSED_WAVE
     for (int i = tid; i < N / 4; i += FUSED_WAVES * 64)
         s_win[i] = *reinterpret_cast<const float4 *>(win + 4 * i); // (src/psd.rs:44-48 table)
 
-#if PSDK_FOLD
+#if PSDK_FOLD && !PSDK_AUX_BACK
     int bid = (int)blockIdx.x - aux.nblocks;
 #else
     int bid = blockIdx.x;
