@@ -869,6 +869,37 @@ def test_many_scattered_spans_share_a_round(pkg, ora, gpu_required, n, piece_log
     g2.close()
 
 
+@pytest.mark.parametrize("n,piece,merge", [(1024, 4096, True), (256, 12288, True), (512, 8192, False)])
+def test_hold_and_merge_caps_at_small_sizes(pkg, ora, gpu_required, monkeypatch, n, piece, merge):
+    """The caps on a merged span (2^29 samples) and on what a channel holds (2^29; a handle of one channel 2^30) are reached by the
+    bench and by `test_round_of_sixteen_full_size_spans` only; here they are brought down to 2^16 / 2^17 (`PSDC_DBG_HOLD_LOG2`, read
+    when the handle is made -- the switch `tests/host/round_plan_check.cpp` uses on the CPU model) so that a stream of 2^19 samples
+    runs through them on the real kernels: contiguous pieces grow a span to its cap, the next piece starts a new span behind a seam,
+    the round goes out when the channel holds its cap -- against the oracle, with a read-out in the middle."""
+    import torch
+    total = (1 << 19) + 3 * n + 20
+    x = make_signal(pkg, total, seed=9100 + n, tone=0.15, dc=0.02)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("PSDC_DBG_HOLD_LOG2", "16")
+    g = pkg.PsdCascadeBank(n, 1)
+    monkeypatch.delenv("PSDC_DBG_HOLD_LOG2")
+    g.configure(profile=True, merge=merge)
+    a, i = 0, 0
+    while a < total:
+        m = min(piece + (8 * (i % 3) if i % 5 else 4), total - a)  # (pieces of three lengths, every fifth one not a multiple of eight)
+        g.process_device(0, xd.data_ptr() + 4 * a, m)
+        a += m
+        i += 1
+        if a > total // 2 and a - m <= total // 2:
+            assert g.stage_info(0, 0)["count"] > 0  # (a read-out sends out what is held)
+    g.sync()
+    launches = g.profile_read()["launches"]
+    assert launches >= (total >> 17) - 1, launches  # a round at least every 2^17 samples: the cap was in force
+    check_against_oracle(pkg, ora, g, [x], n, what=f"caps 2^16 / 2^17, N={n}, pieces of {piece}, merge {merge}")
+    g.close()
+
+
 def test_round_of_sixteen_full_size_spans(pkg, ora, gpu_required):
     """BASELINE config 2's span (2^26 samples, N = 1024) seventeen times over: a handle of one channel holds sixteen such spans and
     sends them out as ONE round of 2^30 samples (csrc/host_runtime.h hold_max; `bench.py`'s step).  The stream is too long for the
