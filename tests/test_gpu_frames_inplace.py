@@ -142,6 +142,36 @@ def test_contiguous_frame_calls_merge_into_one_run(pkg, ora, gpu_required, n, ba
     many.close()
 
 
+@pytest.mark.parametrize("n,batches", [(1024, 22), (256, 9)])
+def test_merged_frame_runs_stop_at_the_hold_cap(pkg, ora, gpu_required, monkeypatch, n, batches):
+    """... and a merged run stops growing where its traces would hold more than the cap (2^29 samples a trace; here 2^15,
+    `PSDC_DBG_HOLD_LOG2` read when the handle is made): the next call starts a new run of the four traces behind seams, and rounds go
+    out as the cap fills -- a capture ring handed over in calls of a few frames, every trace against the oracle, Loss exact."""
+    import torch
+    per_frame = 8 * batches
+    nframes = (5 << 15) // per_frame + 37  # five caps' worth of samples a trace
+    buf, fs, traces = make_frames(pkg, ora, nframes, batches, seed=3 * n + batches, seq0=17)
+    d = torch.from_numpy(buf.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("PSDC_DBG_HOLD_LOG2", "15")
+    g = pkg.PsdCascadeBank(n, 4)
+    monkeypatch.delenv("PSDC_DBG_HOLD_LOG2")
+    g.configure(profile=True)
+    rng = np.random.default_rng(n + batches)
+    pos = 0
+    first = -(-4 * (n + 288) // per_frame) + 1
+    while pos < nframes:
+        m = first if pos == 0 else int(min(nframes - pos, rng.integers(1, 60)))
+        assert g.process_adcdac_frames_device(d.data_ptr() + pos * fs, fs, m) == m
+        pos += m
+    g.sync()
+    assert g.profile_read()["launches"] >= 4  # (one round would be a cap that was not in force)
+    assert g.loss() == {"received": nframes * batches, "dropped": 0}
+    for c in range(4):
+        check_against_oracle(pkg, ora, g, [traces[c]], n, channel=c, what=f"merged frame runs under a 2^15 cap, trace {c}")
+    g.close()
+
+
 def test_headers_may_change_once_the_call_has_returned(pkg, ora, gpu_required):
     """include/psdcascade.h, psdc_process_adcdac_frames_device, Lifetime: the verdict launch is the only reader of the 8 header
     bytes and has completed when the call returns -- the payload is read later (held spans share rounds; the tail of a span is
