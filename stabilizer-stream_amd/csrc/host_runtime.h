@@ -28,7 +28,10 @@ namespace psdrt {
 using namespace psdk;
 
 constexpr uint32_t MAX_STAGES = 16; // 8^16 N samples: unreachable; slots of the spectra slab
-constexpr int MAX_COALESCE = 64; // zero-copy spans of one channel in one round (the automatic depth for one channel fed in short f32 spans)
+#ifndef PSDC_MAX_COALESCE
+#define PSDC_MAX_COALESCE 128
+#endif
+constexpr int MAX_COALESCE = PSDC_MAX_COALESCE; // zero-copy spans of one channel in one round (the automatic depth for one channel fed in short f32 spans)
 constexpr int MAX_COALESCE_OPT = 16; // ... as an explicit PSDC_OPT_COALESCE, and for runs of AdcDac frames: a launch's frame-span table
 // ... and samples a channel holds back at most (hold_max below): what eight 2^26-sample spans make -- sixteen for a handle of ONE channel,
 // whose round is all its own (a 2^30-sample round of sixteen 2^26-sample spans reads 1.0-1.7 % above two of eight: half the launch

@@ -12,10 +12,11 @@
 namespace psdk {
 
 #ifndef PSDK_MAX_JOBS
-// 160: a round of sixty-four scattered f32 spans of one channel (two jobs a span + its deep stages: ~139) is ONE fused and ONE post
-// launch (round 5; 128 split it into two of each: scattered 2^16-sample calls 62 -> 73 GS/s, 2^20 446 -> 483, headline and eight channels
-// unchanged; measured with 192)
-#define PSDK_MAX_JOBS 160
+// 320: a round of 128 scattered f32 spans of one channel (two jobs a span + its deep stages: ~270) is ONE launch.  (128 until round 5,
+// then 160 for sixty-four spans a round; every kernel found its job by a LINEAR scan of this table then -- ~0.1 us a job in front of
+// every workgroup -- so longer tables cost what they saved.  With the bisection: 64 -> 128 spans a round reads scattered 2^16 / 2^18 /
+// 2^20-sample calls 210 / 433 / 570 -> 235 / 498 / 605 GS/s, 2^22 and the headline unchanged.)
+#define PSDK_MAX_JOBS 320
 #endif
 constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
 
@@ -198,7 +199,10 @@ struct TailBatch {
 // fold the partials of the round BEFORE (the other partial slab) and carry this round's stream tails -- neither depends on anything
 // this launch writes --, and jobs [ntail, ntail + npre) of `tail` are copy PROLOGUES of single-workgroup fused jobs (the seams: the
 // head of a new span behind the carried tail), named by FusedJob::pre_first / pre_count.
-constexpr int AUX_MAX_RED = 96, AUX_MAX_TAIL = 160, AUX_RED_BINS = 16;
+#ifndef PSDK_AUX_MAX_TAIL
+#define PSDK_AUX_MAX_TAIL 320
+#endif
+constexpr int AUX_MAX_RED = 96, AUX_MAX_TAIL = PSDK_AUX_MAX_TAIL, AUX_RED_BINS = 16;
 constexpr int AUX_SHORT_ROWS = 4, AUX_MID_ROWS = 64, AUX_MID_GROUPS = 8; // the three shapes of a fold job, by its partial rows
 struct FusedAux {
     int nblocks;    // aux workgroups in front of the compute workgroups: red_blocks + ntail

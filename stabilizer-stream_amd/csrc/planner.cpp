@@ -512,7 +512,7 @@ void Round::share_workgroups()
                 return a.j.s_off < b.j.s_off;
             return a.j.fch < b.j.fch;
         });
-    // Fused jobs per launch: all MAX_JOBS for a single channel (a round of sixty-four scattered spans is then ONE launch), 128 for
+    // Fused jobs per launch: all MAX_JOBS for a single channel (a round of 128 scattered spans is then ONE launch), 128 for
     // several channels -- eight channels x eight spans (208 jobs) measured 4 % SLOWER as one launch of 160 + one of 48 than as 128 + 80
     // (658 vs 685-691 GS/s, kernel-only 0.335 vs 0.352: each launch gets the one run length that fills the GPU for ITS jobs)
 #ifndef PSDK_MULTI_JPL

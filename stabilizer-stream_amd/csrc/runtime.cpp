@@ -483,7 +483,7 @@ int collect_profile(psdc_handle *h)
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
 {
     if (h->coalesce_auto && h->n_channels == 1) {
-        // sixteen spans a round (2^30 samples of 2^26-sample spans: hold_max), up to sixty-four spans shorter than 2^24 samples -- rounds
+        // sixteen spans a round (2^30 samples of 2^26-sample spans: hold_max), up to 128 spans shorter than 2^24 samples -- rounds
         // of about 2^28 (round 5: spans that do NOT continue each other in memory -- those merge -- at 2^22 / 2^20 / 2^18 / 2^16 samples a
         // call: tests/host/devcall_probe "scattered")
         const size_t m = std::max<size_t>(std::max(c.span_max, len), 1);

@@ -265,7 +265,7 @@ void scenario_spans(uint64_t seed)
     Rng r(seed);
     static const uint32_t sizes[] = {256, 512, 1024, 2048, 4096, 8192, 16384, 1024};
     const uint32_t n = sizes[seed % 8];
-    // (one seed in five: ONE channel at the library's own coalescing depth -- up to sixty-four short spans in a round, ~140 fused jobs)
+    // (one seed in five: ONE channel at the library's own coalescing depth -- up to 128 short spans in a round, ~270 fused jobs)
     const bool deep = seed % 5 == 2;
     const int nch = deep ? 1 : (int)r.u(1, 9);
     const int caps[] = {0, 2, 5, 16, 64};
@@ -439,6 +439,7 @@ void scenario_hold_rules()
     const size_t piece = 4096, span = 8192; // (a span is read in place from 4 (n + 288) = 2176 samples)
     struct Case {
         const char *what;
+        int hold_log2;       // PSDC_DBG_HOLD_LOG2 for the handle (0: the library's caps, far out of reach here)
         int merge, coalesce; // coalesce 0: the library's own depth
         bool contiguous;     // pieces of one array in order (they continue each other in memory), or every span an array of its own
         size_t len;
@@ -447,19 +448,23 @@ void scenario_hold_rules()
     };
     static const Case cases[] = {
         // pieces 0 ... 15 grow one span to its cap, 16 ... 31 a second one; the channel then holds 2^17 samples: out with piece 31, 63
-        {"hold rules: contiguous pieces merge", 1, 0, true, piece, 70, [](int i) { return i % 32 == 31; }},
+        {"hold rules: contiguous pieces merge", 16, 1, 0, true, piece, 70, [](int i) { return i % 32 == 31; }},
         // the library's depth for 8192-sample spans is 64; sixteen of them are 2^17 samples: out with the 16th, 32nd ... call
-        {"hold rules: scattered spans, the library's depth", 1, 0, false, span, 40, [](int i) { return i % 16 == 15; }},
+        {"hold rules: scattered spans, the library's depth", 16, 1, 0, false, span, 40, [](int i) { return i % 16 == 15; }},
         // an explicit depth of four: the round goes out with the call that cannot join it (the fifth, ninth ...), which is then held
-        {"hold rules: four spans a round", 0, 4, false, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
+        {"hold rules: four spans a round", 16, 0, 4, false, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
         // ... also when the spans continue each other in memory but merging is off
-        {"hold rules: four spans a round, contiguous, no merging", 0, 4, true, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
+        {"hold rules: four spans a round, contiguous, no merging", 16, 0, 4, true, span, 14, [](int i) { return i > 0 && i % 4 == 0; }},
+        // the library's caps: spans just long enough to be read in place are held 128 to a round (MAX_COALESCE; ~270 fused jobs in ONE
+        // launch), which goes out with the 129th, 257th ... call
+        {"hold rules: 128 short spans a round", 0, 1, 0, false, 2304, 300, [](int i) { return i > 0 && i % 128 == 0; }},
         // depth one: nothing is ever held
-        {"hold rules: every span its own round", 1, 1, false, span, 6, [](int) { return true; }},
+        {"hold rules: every span its own round", 16, 1, 1, false, span, 6, [](int) { return true; }},
     };
     for (const Case &cs : cases) {
         new_scenario(cs.what, 0);
-        setenv("PSDC_DBG_HOLD_LOG2", "16", 1);
+        if (cs.hold_log2)
+            setenv("PSDC_DBG_HOLD_LOG2", std::to_string(cs.hold_log2).c_str(), 1);
         psdc_handle *h = psdc_create(n, PSDC_WINDOW_HANN, 1, 0);
         unsetenv("PSDC_DBG_HOLD_LOG2");
         if (!h) {
