@@ -15,7 +15,8 @@ namespace psdk {
 // 320: a round of 128 scattered f32 spans of one channel (two jobs a span + its deep stages: ~270) is ONE launch.  (128 until round 5,
 // then 160 for sixty-four spans a round; every kernel found its job by a LINEAR scan of this table then -- ~0.1 us a job in front of
 // every workgroup -- so longer tables cost what they saved.  With the bisection: 64 -> 128 spans a round reads scattered 2^16 / 2^18 /
-// 2^20-sample calls 210 / 433 / 570 -> 235 / 498 / 605 GS/s, 2^22 and the headline unchanged.)
+// 2^20-sample calls 210 / 433 / 570 -> 235 / 498 / 605 GS/s, 2^22 and the headline unchanged.  There is a cliff further out: 640 jobs --
+// about 90 KB of kernel arguments with the aux table -- read 71 / 95 / 104 GS/s, five times slower.)
 #define PSDK_MAX_JOBS 320
 #endif
 constexpr int MAX_JOBS = PSDK_MAX_JOBS; // jobs per launch (they travel in the kernel-argument segment)
