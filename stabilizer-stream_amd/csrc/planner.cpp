@@ -512,13 +512,19 @@ void Round::share_workgroups()
                 return a.j.s_off < b.j.s_off;
             return a.j.fch < b.j.fch;
         });
-    // Fused jobs per launch: all MAX_JOBS for a single channel (a round of 128 scattered spans is then ONE launch), 128 for
-    // several channels -- eight channels x eight spans (208 jobs) measured 4 % SLOWER as one launch of 160 + one of 48 than as 128 + 80
-    // (658 vs 685-691 GS/s, kernel-only 0.335 vs 0.352: each launch gets the one run length that fills the GPU for ITS jobs)
+    // Fused jobs per launch: all MAX_JOBS for a single channel (a round of 128 scattered spans is then ONE launch) and for several
+    // channels fed in spans of at most 2^23 samples (eight channels x 2^22: 651 against 614 GS/s, four x sixteen 2^20-sample spans 587
+    // against 491); 128 for several channels fed in longer spans -- eight channels x eight 2^24-sample spans (208 jobs) measured 2.6 %
+    // SLOWER as one launch than as 128 + 80 (656 against 674 GS/s, kernel-only 0.331 against 0.345: each launch gets the one run length
+    // that fills the GPU for ITS jobs, and in the bench the fewer channels a launch covers the more of their re-fed buffers stay in
+    // the Infinity Cache).  The longest span a channel has SEEN decides: a function of the calls alone.
 #ifndef PSDK_MULTI_JPL
 #define PSDK_MULTI_JPL 128
 #endif
-    fused_jpl = h->n_channels == 1 ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, PSDK_MULTI_JPL);
+    size_t longest = 0;
+    for (const Channel &c : h->ch)
+        longest = std::max(longest, c.span_max);
+    fused_jpl = h->n_channels == 1 || longest <= ((size_t)1 << 23) ? (size_t)MAX_JOBS : std::min<size_t>(MAX_JOBS, PSDK_MULTI_JPL);
     for (size_t b0 = 0; b0 < fjobs.size(); b0 += fused_jpl) {
         const size_t b1 = std::min(fjobs.size(), b0 + fused_jpl);
         // One run length R for the whole launch: the smallest R for which the jobs' workgroups

@@ -482,14 +482,18 @@ int collect_profile(psdc_handle *h)
 // device at once.
 uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
 {
-    if (h->coalesce_auto && h->n_channels == 1) {
+    if (!h->coalesce_auto)
+        return h->coalesce;
+    const size_t m = std::max<size_t>(std::max(c.span_max, len), 1);
+    if (h->n_channels == 1) {
         // sixteen spans a round (2^30 samples of 2^26-sample spans: hold_max), up to 128 spans shorter than 2^24 samples -- rounds
         // of about 2^28 (round 5: spans that do NOT continue each other in memory -- those merge -- at 2^22 / 2^20 / 2^18 / 2^16 samples a
         // call: tests/host/devcall_probe "scattered")
-        const size_t m = std::max<size_t>(std::max(c.span_max, len), 1);
         return (uint32_t)std::min<size_t>(MAX_COALESCE, std::max<size_t>(16, ((size_t)1 << 28) / m));
     }
-    return h->coalesce;
+    // several channels: eight a channel, up to sixteen of short spans -- rounds of about 2^28 samples over all channels (four channels
+    // fed in 2^20-sample spans: 587 against 502 GS/s with the one launch such a round then is, planner.cpp share_workgroups)
+    return (uint32_t)std::min<size_t>(MAX_COALESCE_OPT, std::max<size_t>(h->coalesce, ((size_t)1 << 28) / (m * h->n_channels)));
 }
 
 bool holds_short_span(const psdc_handle *h, const Channel &c)
