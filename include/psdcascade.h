@@ -80,8 +80,8 @@ extern "C" {
 
 /* options for psdc_configure */
 #define PSDC_OPT_QUANTUM 1 /* host-fed samples buffered per channel before a launch (default 1<<22) */
-#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8 -- up to 16 of short spans,
-                             * so that a round of all channels holds ~2^28 samples -- and at most 2^29 samples a channel; a handle of ONE channel: 16 and at most 2^30 samples, and of f32 spans shorter than 2^24 samples
+#define PSDC_OPT_COALESCE 3 /* in-place device spans of a channel that share one round (1..16; default: 8 -- more of short spans,
+                             * so that a round of all channels holds ~2^28 samples and stays one launch -- and at most 2^29 samples a channel; a handle of ONE channel: 16 and at most 2^30 samples, and of f32 spans shorter than 2^24 samples
                              * as many as make a round of ~2^28 samples, up to 128 -- a round costs 5 ... 20 us whatever it holds;
                              * 1 = every span its own round).  A span is HELD until its channel holds that many samples or a call arrives
                              * that cannot join them (one span more than that many, host-fed or short spans, settings changes, every

@@ -491,9 +491,12 @@ uint32_t coalesce_limit(const psdc_handle *h, const Channel &c, size_t len)
         // call: tests/host/devcall_probe "scattered")
         return (uint32_t)std::min<size_t>(MAX_COALESCE, std::max<size_t>(16, ((size_t)1 << 28) / m));
     }
-    // several channels: eight a channel, up to sixteen of short spans -- rounds of about 2^28 samples over all channels (four channels
-    // fed in 2^20-sample spans: 587 against 502 GS/s with the one launch such a round then is, planner.cpp share_workgroups)
-    return (uint32_t)std::min<size_t>(MAX_COALESCE_OPT, std::max<size_t>(h->coalesce, ((size_t)1 << 28) / (m * h->n_channels)));
+    // several channels: eight a channel, more of short spans -- rounds of about 2^28 samples over all channels, as many spans as keep
+    // the round ONE launch (two jobs a span and about twelve deep stages a channel within MAX_JOBS: 34 a channel for four channels, 14
+    // for eight; planner.cpp share_workgroups).  Four channels fed in 2^20-sample spans: 502 GS/s at eight, 587 at sixteen
+    const size_t fit = ((size_t)MAX_JOBS - std::min<size_t>(MAX_JOBS / 2, (size_t)12 * h->n_channels)) / ((size_t)2 * h->n_channels);
+    const size_t most = std::min<size_t>(MAX_COALESCE, std::max<size_t>(h->coalesce, fit));
+    return (uint32_t)std::min<size_t>(most, std::max<size_t>(h->coalesce, ((size_t)1 << 28) / (m * h->n_channels)));
 }
 
 bool holds_short_span(const psdc_handle *h, const Channel &c)

@@ -869,6 +869,51 @@ def test_many_scattered_spans_share_a_round(pkg, ora, gpu_required, n, piece_log
     g2.close()
 
 
+@pytest.mark.parametrize("n,nch,piece_log2,npieces", [(512, 4, 13, 80), (1024, 8, 14, 30), (256, 2, 12, 150)])
+def test_several_channels_short_scattered_spans(pkg, ora, gpu_required, n, nch, piece_log2, npieces):
+    """Several channels fed in lockstep in short spans that do not continue each other in memory, at the library's own depth: as many
+    spans a channel as keep the round ONE launch (34 for four channels, 14 for eight, 74 for two: csrc/runtime.cpp coalesce_limit) --
+    every span a seam region of its own, some 280 fused jobs a launch.  Counters, pending samples and spectra of every channel against
+    the oracle, a read-out in the middle, far fewer launches than eight spans a round would take, and the same calls twice give the
+    same bits."""
+    import torch
+    m = 1 << piece_log2
+    xs = [make_signal(pkg, m * npieces, seed=8800 + 16 * n + c, tone=0.1 + 0.05 * c, dc=0.01 * c) for c in range(nch)]
+    slot = np.random.default_rng(n + nch).permutation(npieces)
+    slot = [int(v) for v in slot]
+    for i in range(1, npieces):  # no span may follow its predecessor in memory
+        if slot[i] == slot[i - 1] + 1:
+            slot[i], slot[(i + 1) % npieces] = slot[(i + 1) % npieces], slot[i]
+    xd = []
+    for x in xs:
+        buf = np.empty_like(x)
+        for i in range(npieces):
+            buf[m * slot[i]:m * (slot[i] + 1)] = x[m * i:m * (i + 1)]
+        xd.append(torch.from_numpy(buf).cuda())
+    torch.cuda.synchronize()
+
+    def run():
+        g = pkg.PsdCascadeBank(n, nch)
+        g.configure(profile=True)
+        for i in range(npieces):
+            for c in range(nch):
+                g.process_device(c, xd[c].data_ptr() + 4 * m * slot[i], m)
+            if i == npieces // 2:
+                assert g.stage_info(nch - 1, 0)["count"] > 0  # (a read-out flushes whatever is held)
+        g.sync()
+        return g
+
+    g, g2 = run(), run()
+    launches = g.profile_read()["launches"]
+    assert launches <= 4 * (npieces // 14 + 1) // 2 + 24, f"{launches} fused launches for {npieces} spans a channel: the rounds stayed shallow"
+    for c in range(nch):
+        for k in range(g.num_stages(c)):
+            assert np.array_equal(g.stage_spectrum(c, k).view(np.uint32), g2.stage_spectrum(c, k).view(np.uint32)), (c, k)
+        check_against_oracle(pkg, ora, g, [xs[c]], n, channel=c, what=f"{nch} channels x {npieces} scattered spans of 2^{piece_log2}, channel {c}")
+    g.close()
+    g2.close()
+
+
 @pytest.mark.parametrize("n,piece,merge", [(1024, 4096, True), (256, 12288, True), (512, 8192, False)])
 def test_hold_and_merge_caps_at_small_sizes(pkg, ora, gpu_required, monkeypatch, n, piece, merge):
     """The caps on a merged span (2^29 samples) and on what a channel holds (2^29; a handle of one channel 2^30) are reached by the
