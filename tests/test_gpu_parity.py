@@ -828,7 +828,7 @@ def test_contiguous_device_calls_merge_into_one_span(pkg, ora, gpu_required, n, 
     many.close()
 
 
-@pytest.mark.parametrize("n,piece_log2,npieces", [(1024, 16, 300), (256, 14, 200), (4096, 17, 70)])
+@pytest.mark.parametrize("n,piece_log2,npieces", [(1024, 16, 300), (256, 14, 200), (4096, 17, 70), (16384, 17, 150)])
 def test_many_scattered_spans_share_a_round(pkg, ora, gpu_required, n, piece_log2, npieces):
     """One channel fed in short spans that do NOT continue each other in memory (pieces of one buffer in a permuted order: nothing merges):
     the library's own coalescing depth makes rounds of about 2^28 samples, i.e. up to 128 spans a round here (round 5; an explicit
